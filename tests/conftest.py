@@ -1,0 +1,66 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    # gpu-marked tests are skipped (not failed) when no device is present and -m gpu was not forced
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for it in items:
+        if 'gpu' in it.keywords:
+            it.add_marker(skip)
+
+
+class Golden:
+    """Lazy view of one tests/golden/*.npz with ':'-prefixed groups."""
+
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+    def t(self, key):
+        a = self.z[key]
+        return torch.from_numpy(np.array(a))
+
+    def group(self, prefix):
+        return {k[len(prefix):]: torch.from_numpy(np.array(self.z[k])) for k in self.z.files if k.startswith(prefix)}
+
+    def keys(self):
+        return list(self.z.files)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+@pytest.fixture(scope='session')
+def pkg():
+    """The product package (directory name has a hyphen, so import it by string)."""
+    return importlib.import_module('video-graph-ssl_amd')
+
+
+def rel_err(a, b):
+    """max |a-b| / max(|b|) -- the 'relative fp32' measure used for the 1e-3 bar."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
