@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build libgca_hip.so for gfx950 (cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")/video-graph-ssl_amd/csrc"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -Wall -Wno-unused-function"
+objs=""
+for f in conv3d bn pool misc infonce graph; do
+  $HIPCC $FLAGS -c $f.hip -o $f.o &
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libgca_hip.so conv3d.o bn.o pool.o misc.o infonce.o graph.o
+ls -la ../libgca_hip.so

@@ -1,0 +1,233 @@
+/*
+ * gca_hip.h -- C ABI of libgca_hip.so: the MI355X (gfx950) kernels behind the GCA
+ * contrastive pre-training hot path (encoder -> graph block -> head -> MoCo queue / InfoNCE).
+ *
+ * The reference (ACMMM2021-Anonymous/video-graph-ssl) is pure Python: it has no FFI layer,
+ * every "kernel" is an ATen/cuDNN call made through torch.nn.  Each entry point below
+ * therefore cites the reference call site (file:line under /root/reference) whose
+ * arithmetic it replaces.  Conventions for every function:
+ *
+ *   - plain device pointers + sizes, fp32 data, NCDHW contiguous activations;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); nothing synchronises;
+ *   - no hidden allocations: workspaces are caller-owned, sizes come from the *_ws_bytes() queries;
+ *   - return 0 on success, negative on invalid arguments (GCA_EINVAL) or launch failure
+ *     (GCA_ELAUNCH); no exceptions cross the ABI.
+ *
+ * The host side (Python, ctypes) lives in video-graph-ssl_amd/_hip.py; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ */
+#ifndef GCA_HIP_H
+#define GCA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GCA_OK 0
+#define GCA_EINVAL (-1)
+#define GCA_ELAUNCH (-2)
+
+int gca_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * 3D convolution as an MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM, NCDHW, no bias.
+ * Replaces every nn.Conv3d on the path: resnet2p1d.py:13-36,162-174; s3d_1.py:40,53,57;
+ * resnet.py:14-22,77-78,120-126; temporal_graph.py:46,119-122 (1x1x1); nn.Linear of the heads
+ * (project_head.py:23-28,39-50) runs through the same kernels as a 1x1x1 conv on (b,C,1,1,1).
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t N, C, D, H, W;       /* input  (N,C,D,H,W)            */
+  int32_t K;                   /* output channels               */
+  int32_t kd, kh, kw;          /* kernel                        */
+  int32_t sd, sh, sw;          /* stride                        */
+  int32_t pd, ph, pw;          /* zero padding                  */
+  int32_t OD, OH, OW;          /* output spatial (caller-computed, checked) */
+  int64_t x_batch_stride;      /* elements between consecutive clips of x; 0 = C*D*H*W (contiguous).
+                                  Lets the two views of a (b,6,T,H,W) batch be read in place
+                                  (tools/train_video_contrast_dis.py:404 torch.chunk on dim 1).
+                                  Honoured by gca_conv_fwd and gca_conv_wgrad; dgrad needs 0. */
+} gca_conv_geom;
+
+/* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward
+ * ([C*taps -> pad16][K -> pad64]), 1 = dgrad ([K*taps -> pad16][C -> pad64]).
+ * gca_conv_pack_elems() gives the float count of the packed buffer. */
+int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which);
+int gca_conv_pack(const gca_conv_geom* g, int which, const float* w, float* packed, void* stream);
+
+/* Gather table (one int2 per packed k-row: element offset + packed tap deltas); built on the
+ * host once per geometry.  which as above, 2 = wgrad (same rows as forward). */
+int64_t gca_conv_table_rows(const gca_conv_geom* g, int which);
+int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_host /* 2*rows ints */);
+
+/* y = conv(x, w) [+ bias[k]].  `wpack` from gca_conv_pack(which=0), `table` device copy of
+ * the which=0 table.  If stat_sum/stat_sq are non-NULL the epilogue also writes per-channel
+ * partial sums / sums of squares of y (training-mode BatchNorm statistics, fused):
+ * layout [K][P], P = gca_conv_fwd_stat_parts(g). */
+int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
+int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, const int32_t* table,
+                 const float* bias, float* y, float* stat_sum, float* stat_sq, void* stream);
+
+/* dx (+)= conv_transpose(dy, w).  `wpack`/`table` from which=1.  accumulate != 0 adds into dx. */
+int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, const int32_t* table,
+                   float* dx, int accumulate, void* stream);
+
+/* dw (+)= sum_{n,o} dy[n,k,o] * x[n,c,o*s-p+tap].  `table` from which=2.  Split-K partial slabs go
+ * to `ws` (gca_conv_wgrad_ws_bytes) and are reduced deterministically. */
+int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g);
+int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
+                   float* dw, int accumulate, void* ws, void* stream);
+
+/* db[k] (+)= sum over (n, spatial) of dy[n,k,:]   (bias gradient of the nn.Linear layers) */
+int gca_bias_grad(const float* dy, int64_t N, int64_t K, int64_t SP, float* db, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm (training mode: batch statistics + running-stat update), fused with ReLU and the
+ * residual add.  Replaces nn.BatchNorm3d/1d + ReLU + `out += residual`:
+ * resnet2p1d.py:49-57,66-85; s3d_1.py:41-47,54-68; project_head.py:39-50,64-68.
+ * Data layout (N, C, SP) with SP = D*H*W (1 for BatchNorm1d).
+ * ------------------------------------------------------------------------------------- */
+/* From conv-epilogue partials [C][P] (or computed by gca_bn_stats): mean/invstd (saved for
+ * backward), running stats update (momentum, unbiased var), and the folded affine
+ * scale = gamma*invstd, shift = beta - mean*scale.  count = N*SP. */
+int gca_bn_stats(const float* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
+                 int64_t* parts_out, void* stream);          /* P is fixed: gca_bn_stats_parts() */
+int64_t gca_bn_stats_parts(int64_t N, int64_t C, int64_t SP);
+int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+/* Eval-mode fold (running stats): scale/shift only. */
+int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, int64_t C, float* scale, float* shift, void* stream);
+/* z = [relu]( x*scale[c] + shift[c] [+ residual] ).  z_batch_stride (elements; 0 = C*SP) lets z be a
+ * channel slice of a wider (N, Ctot, SP) buffer: the Inception branches write straight into their
+ * slice of the concat output (s3d_1.py:96 torch.cat) instead of being copied there. */
+int gca_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
+                 int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream);
+/* Backward of the fused op.  dz_in = gradient wrt z; z = saved output (ReLU mask); x = saved conv
+ * output.  Writes dx (gradient wrt x), accumulates dgamma/dbeta (+=) and, if dres != NULL,
+ * writes (dres_accumulate=0) or adds (=1) the gradient wrt the residual input.
+ * ws: gca_bn_bwd_ws_bytes(). */
+int64_t gca_bn_bwd_ws_bytes(int64_t N, int64_t C, int64_t SP);
+int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* gamma,
+               const float* save_mean, const float* save_invstd, int relu,
+               int64_t N, int64_t C, int64_t SP, float* dx, float* dgamma, float* dbeta,
+               float* dres, int dres_accumulate, int64_t z_batch_stride /* of dz_in and z */,
+               void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Pooling.  MaxPool3d: resnet2p1d.py:178, s3d_1.py:10,13,16,22,87, temporal_graph.py:100
+ * (first-max tie break in (d,h,w) scan order, as ATen).  Global/temporal-weighted average:
+ * resnet2p1d.py:197,260 (AdaptiveAvgPool3d(1)); s3d_1.py:30-33 (avg_pool3d((2,H,W),1) then mean
+ * over T' == frame-weighted global mean); resnet.py:137-140,187.
+ * ------------------------------------------------------------------------------------- */
+typedef struct {
+  int32_t N, C, D, H, W;
+  int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
+  int32_t OD, OH, OW;
+} gca_pool_geom;
+int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, void* stream);
+int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* argmax, float* dx,
+                      int accumulate, void* stream);
+/* y[n,c] = sum_{d,h,w} wt[d] * x[n,c,d,h,w] * norm   (wt == NULL -> all ones) */
+int gca_wavgpool_fwd(const float* x, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
+                     float* y, void* stream);
+int gca_wavgpool_bwd(const float* dy, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
+                     float* dx, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Head pieces.  ReLU between the two Linear layers (project_head.py:24-27) and row L2
+ * normalisation `Normalize` (project_head.py:4-10, F.normalize eps 1e-12).
+ * ------------------------------------------------------------------------------------- */
+int gca_relu_fwd(const float* x, int64_t n, float* y, void* stream);
+int gca_relu_bwd(const float* dy, const float* y, int64_t n, float* dx, void* stream);
+int gca_l2norm_fwd(const float* x, int64_t rows, int64_t dim, float eps, float* y, float* inv_norm, void* stream);
+int gca_l2norm_bwd(const float* dy, const float* y, const float* inv_norm, int64_t rows, int64_t dim,
+                   float* dx, void* stream);
+/* Negative cosine similarity D(p, stopgrad(z)) of SimSiam (graph_wrappers.py:105-106):
+ * loss[0] (+)= -scale * mean_i cos(p_i, z_i); dp = d loss / d p.  `loss` needs 1 + rows floats
+ * (loss[1..rows] receives the per-row cosines). */
+int gca_negcos_fwd_bwd(const float* p, const float* z, int64_t rows, int64_t dim, float scale,
+                       float* loss, int accumulate, float* dp, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MoCo queue + InfoNCE.  RGBMoCo._compute_logit (lib/memory/mem_moco.py:29-49):
+ * logits[i,0] = q_i.k_i / T, logits[i,1+j] = q_i.queue_j / T, as one clip x queue MFMA GEMM
+ * streaming the queue once.  NCESoftmaxLoss (lib/memory/criterion.py:34-45) = mean_i
+ * (logsumexp(logits_i) - logits_i0).  _update_memory/_update_pointer (mem_moco.py:14-27).
+ * ------------------------------------------------------------------------------------- */
+/* logits (b, K+1).  Optional fused row statistics (any may be NULL): row_lse (b), and
+ * rank_ge (b) = number of negatives with logit >= the positive's (top-1 hit <=> 0, top-5 <=> < 5;
+ * lib/evaluation/metric.py:44-67 with label 0).  ws: gca_infonce_ws_bytes(b, K). */
+int64_t gca_infonce_ws_bytes(int64_t b, int64_t K);
+int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
+                        int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge,
+                        void* ws, void* stream);
+/* loss = mean_i (lse_i - logits[i,0]); lse computed here if row_lse_in == NULL. */
+int gca_nce_softmax_loss_fwd(const float* logits, int64_t b, int64_t ncol, const float* row_lse_in,
+                             float* row_lse_out, float* loss, void* stream);
+/* dlogits[i,j] = gscale * (softmax(logits_i)[j] - [j==0]) / b   (gscale: upstream d loss) */
+int gca_nce_softmax_loss_bwd(const float* logits, const float* row_lse, int64_t b, int64_t ncol,
+                             const float* gscale_dev, float gscale_host, float* dlogits, void* stream);
+/* dq = dlogits[:,0:1]*k/T + dlogits[:,1:] @ queue / T.  Rows [ov_start, ov_start+ov_n) mod K of
+ * `queue` are read from ov_rows instead (the rows the enqueue of this step has already
+ * overwritten -- the reference computes the gradient against the pre-enqueue snapshot,
+ * mem_moco.py:72).  If dlogits == NULL it is formed on the fly from logits/row_lse as in
+ * gca_nce_softmax_loss_bwd (fused path; no dlogits tensor is materialised). */
+int gca_moco_logits_bwd(const float* dlogits, const float* logits, const float* row_lse,
+                        const float* gscale_dev, float gscale_host,
+                        const float* k, const float* queue, int64_t b, int64_t K, int64_t D, float inv_T,
+                        int64_t ov_start, const int64_t* ov_start_dev /* overrides ov_start if non-NULL */,
+                        int64_t ov_n, const float* ov_rows, float* dq, void* ws, void* stream);
+/* queue[(ptr + i) % K] = keys[i], i < n; optionally saves the overwritten rows first.  The
+ * reference keeps the pointer as a Python int (mem_moco.py:12); for hipGraph replay it can live in
+ * device memory instead: ptr_dev (non-NULL) overrides ptr, gca_queue_advance moves it. */
+int gca_queue_enqueue(float* queue, int64_t K, int64_t D, const float* keys, int64_t n, int64_t ptr,
+                      const int64_t* ptr_dev, float* saved_rows, void* stream);
+int gca_queue_advance(int64_t* ptr_dev, int64_t n, int64_t K, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Temporal-graph block (lib/ops/module_wrappers/temporal_graph.py).  The 1x1x1 convs and the
+ * (1,2,2) max pool go through gca_conv_* / gca_maxpool3d_*; these are the graph-specific parts.
+ * ------------------------------------------------------------------------------------- */
+/* sim = softmax_j( sum_f gq[b,i,f]*gk[b,j,f] ), gq/gk stored (B, Ci, T, HW) as the pooled convs
+ * leave them (temporal_graph.py:159-176); then adj_pre = sim * theta(hop(i,j)) within max_hop
+ * else 0 (:204-210); then adj = sigmoid((logit(u)+logit(adj_pre))/temperature)  (:187-192,
+ * RelaxedBernoulli.rsample with explicit uniforms u).  Any of sim/adj_pre may be NULL. */
+int gca_graph_adj_fwd(const float* gq, const float* gk, int64_t B, int64_t Ci, int64_t T, int64_t HW,
+                      int max_hop, float alpha, float temperature, const float* u,
+                      float* sim, float* adj_pre, float* adj, void* stream);
+/* NOTE: dadj is in/out -- it is overwritten with the gradient wrt the pre-softmax similarity. */
+int gca_graph_adj_bwd(const float* dadj, const float* gq, const float* gk, const float* sim,
+                      const float* adj_pre, const float* adj, int64_t B, int64_t Ci, int64_t T, int64_t HW,
+                      int max_hop, float alpha, float temperature, float* dgq, float* dgk, void* stream);
+/* out[b,c,i,:] = sum_j adj[b,i,j]*s[b,c,j,:] + s[b,c,i,:]   (einsum 'bij,bcjhw->bcihw' + skip,
+ * temporal_graph.py:59-62): wave-reduced dense neighbourhood GEMV, one pass over s. */
+int gca_graph_gcn_fwd(const float* adj, const float* s, int64_t B, int64_t C, int64_t T, int64_t HW,
+                      float* out, void* stream);
+/* ds[b,c,j,:] = sum_i adj[b,i,j]*dout[b,c,i,:] + dout[b,c,j,:];  dadj[b,i,j] = sum_{c,hw} dout[b,c,i,:]*s[b,c,j,:] */
+int64_t gca_graph_gcn_bwd_ws_bytes(int64_t B, int64_t C, int64_t T, int64_t HW);
+int gca_graph_gcn_bwd(const float* adj, const float* s, const float* dout, int64_t B, int64_t C, int64_t T,
+                      int64_t HW, float* ds, float* dadj, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-tensor parameter updates over flat, 256-element-aligned parameter arenas.
+ * _momentum_update (tools/train_video_contrast_dis.py:177-180) and torch.optim.SGD as
+ * configured by make_optimizer (lib/solver/build.py:24-59: one group per parameter).
+ * ------------------------------------------------------------------------------------- */
+int gca_ema_update(float* p_ema, const float* p, int64_t n, float m, void* stream);
+/* seg table: per 256-element chunk i: lr[i], wd[i] (device arrays of length n/256). */
+int gca_sgd_step(float* p, const float* grad, float* mom_buf, int64_t n, const float* chunk_lr,
+                 const float* chunk_wd, float lr_scale, float momentum, int nesterov, int first_step,
+                 void* stream);
+int gca_fill(float* p, int64_t n, float v, void* stream);
+int gca_axpy(float* y, const float* x, int64_t n, float a, void* stream);          /* y += a*x */
+int gca_scale(float* y, int64_t n, float a, void* stream);
+int gca_gather_rows(const float* src, const int64_t* idx, int64_t rows, int64_t row_elems, float* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GCA_HIP_H */

@@ -1,0 +1,317 @@
+"""GPU parity of every kernel family against (a) the committed golden vectors produced by the
+reference's own modules and (b) the CPU oracle / ATen fp32 on seeded inputs, through the C ABI.
+Tolerance: 1e-3 relative (max|a-b| / max|b|) as BASELINE.json's north_star states; most ops are
+checked far tighter (1e-5) because fp32 MFMA is an exact fma chain."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda:0')
+CONVS = ['stem_s', 'stem_t', 's3d_t_s2', 'c1x3x3', 'c1x3x3_s2', 'c3x1x1', 'c3x1x1_s2', 'c1x1x1_s2', 'c1x1x1',
+         'c3x3x3', 'c3x3x3_s2', 'c7x7x7']
+
+
+@pytest.fixture(scope='module')
+def ops(pkg):
+    return pkg.engine.ops
+
+
+def _conv_all(ops, x, w, dy, k, s, p):
+    plan = ops.conv_plan(tuple(x.shape), w.shape[0], k, s, p, x.device)
+    y, (ss, sq) = ops.conv_fwd(plan, x, ops.conv_pack(plan, 0, w), None, stats=True)
+    dx = ops.conv_dgrad(plan, dy, ops.conv_pack(plan, 1, w))
+    dw = torch.zeros_like(w)
+    ops.conv_wgrad(plan, x, dy, dw, accumulate=True)
+    return y, dx, dw, ss.sum(1), sq.sum(1)
+
+
+@pytest.mark.parametrize('name', CONVS)
+def test_conv_golden(ops, golden, name):
+    g = golden('ops')
+    cfg = g.t(name + ':cfg').tolist()
+    x, w, dy = (g.t(name + ':' + t).to(DEV) for t in ('x', 'w', 'dy'))
+    y, dx, dw, s1, s2 = _conv_all(ops, x, w, dy, cfg[0:3], cfg[3:6], cfg[6:9])
+    yr = g.t(name + ':y')
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(dx, g.t(name + ':dx')) < 1e-5
+    assert rel_err(dw, g.t(name + ':dw')) < 1e-5
+    # fused BN statistics from the conv epilogue
+    assert rel_err(s1, yr.sum((0, 2, 3, 4))) < 1e-4
+    assert rel_err(s2, (yr * yr).sum((0, 2, 3, 4))) < 1e-4
+
+
+@pytest.mark.parametrize('shape,K,k,s,p', [
+    ((3, 5, 6, 17, 19), 70, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # ragged N tile, M tail
+    ((2, 130, 4, 9, 9), 200, (3, 1, 1), (2, 1, 1), (1, 0, 0)),      # BM=128 path, K tail, temporal stride
+    ((1, 64, 2, 33, 33), 144, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # strided dgrad (divide mode)
+    ((4, 16, 1, 1, 1), 24, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # a Linear layer
+    ((2, 7, 5, 6, 7), 9, (3, 3, 3), (1, 2, 1), (1, 0, 2)),          # mixed stride / asymmetric padding
+])
+def test_conv_random_vs_aten(ops, shape, K, k, s, p):
+    torch.manual_seed(0)
+    x = torch.randn(shape)
+    w = torch.randn((K, shape[1]) + tuple(k)) * 0.1
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, s, p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    y, dx, dw, _, _ = _conv_all(ops, x.to(DEV), w.to(DEV), dy.to(DEV), k, s, p)
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(dx, xr.grad) < 1e-5
+    assert rel_err(dw, wr.grad) < 1e-5
+
+
+def test_conv_batch_stride_views(ops):
+    """The two views of a (b,6,T,H,W) batch are read in place (tools/...dis.py:404)."""
+    torch.manual_seed(1)
+    img = torch.randn(3, 6, 4, 12, 12)
+    w = torch.randn(10, 3, 1, 7, 7) * 0.1
+    imgd = img.to(DEV)
+    for half in (0, 1):
+        xv = torch.chunk(imgd, 2, dim=1)[half]
+        plan = ops.conv_plan(tuple(xv.shape), 10, (1, 7, 7), (1, 2, 2), (0, 3, 3), DEV, xv.stride(0))
+        y = ops.conv_fwd(plan, xv, ops.conv_pack(plan, 0, w.to(DEV)))
+        xr = torch.chunk(img, 2, dim=1)[half]
+        yr = F.conv3d(xr, w, None, (1, 2, 2), (0, 3, 3))
+        assert rel_err(y, yr) < 1e-5
+        dy = torch.randn_like(yr)
+        dw = torch.zeros_like(w).to(DEV)
+        ops.conv_wgrad(plan, xv, dy.to(DEV), dw, accumulate=True)
+        wr = w.clone().requires_grad_(True)
+        F.conv3d(xr, wr, None, (1, 2, 2), (0, 3, 3)).backward(dy)
+        assert rel_err(dw, wr.grad) < 1e-5
+
+
+def test_conv_bias_and_accumulate(ops):
+    torch.manual_seed(2)
+    x, w, b = torch.randn(5, 12, 1, 1, 1), torch.randn(20, 12, 1, 1, 1), torch.randn(20)
+    plan = ops.conv_plan(tuple(x.shape), 20, 1, 1, 0, DEV)
+    y = ops.conv_fwd(plan, x.to(DEV), ops.conv_pack(plan, 0, w.to(DEV)), b.to(DEV))
+    assert rel_err(y, F.conv3d(x, w, b)) < 1e-5
+    dy = torch.randn(5, 20, 1, 1, 1)
+    base = torch.randn_like(x)
+    dx = base.clone().to(DEV)
+    ops.conv_dgrad(plan, dy.to(DEV), ops.conv_pack(plan, 1, w.to(DEV)), dx, accumulate=True)
+    ref = base + torch.einsum('nk,kc->nc', dy.flatten(1), w.flatten(1)).view_as(x)
+    assert rel_err(dx, ref) < 1e-5
+    db = torch.zeros(20, device=DEV)
+    ops.bias_grad(dy.to(DEV), 5, 20, 1, db, True)
+    assert rel_err(db, dy.sum((0, 2, 3, 4))) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['bn_s3d', 'bn_def'])
+def test_bn_relu_golden(ops, golden, name):
+    g = golden('ops')
+    x = g.t(name + ':x').to(DEV)
+    N, Cc = x.shape[:2]
+    SP = x[0, 0].numel()
+    eps, mom = [float(v) for v in g.t(name + ':hp')]
+    gam, bet = g.t(name + ':g').to(DEV), g.t(name + ':b').to(DEV)
+    rm, rv = g.t(name + ':rm0').to(DEV), g.t(name + ':rv0').to(DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    ss, sq = ops.bn_stats(x, N, Cc, SP)
+    mean, invstd, scale, shift = ops.bn_finalize(ss, sq, N * SP, gam, bet, eps, mom, rm, rv, nbt)
+    z = ops.bn_apply(x, scale, shift, None, True, N, Cc, SP)
+    assert rel_err(z, g.t(name + ':y_relu')) < 1e-5
+    assert rel_err(rm, g.t(name + ':rm1')) < 1e-5 and rel_err(rv, g.t(name + ':rv1')) < 1e-5
+    assert int(nbt) == 1
+    dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    dx = ops.bn_bwd(g.t(name + ':dy').to(DEV), z, x, gam, mean, invstd, True, N, Cc, SP, dg, db)
+    assert rel_err(dx, g.t(name + ':dx')) < 1e-4
+    assert rel_err(dg, g.t(name + ':dg')) < 1e-4 and rel_err(db, g.t(name + ':db')) < 1e-4
+
+
+def test_bn_residual_slice_and_odd_sizes(ops):
+    """residual add, channel-slice output (concat buffer), SP not a multiple of 4, BatchNorm1d (SP=1)."""
+    torch.manual_seed(3)
+    for shape in [(3, 6, 2, 5, 7), (4, 10, 1, 1, 1), (2, 8, 2, 4, 4)]:
+        x = torch.randn(shape) * 1.5 + 0.3
+        res = torch.randn(shape)
+        N, Cc = shape[:2]
+        SP = x[0, 0].numel()
+        bn = torch.nn.BatchNorm3d(Cc)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_()
+        xr, rr = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        zr = F.relu(bn(xr) + rr)
+        dz = torch.randn_like(zr)
+        zr.backward(dz)
+        xd, resd = x.to(DEV), res.to(DEV)
+        gam, bet = bn.weight.data.to(DEV), bn.bias.data.to(DEV)
+        ss, sq = ops.bn_stats(xd, N, Cc, SP)
+        mean, invstd, scale, shift = ops.bn_finalize(ss, sq, N * SP, gam, bet, bn.eps, 0.1, None, None, None)
+        wide = torch.zeros((N, Cc + 5) + shape[2:], device=DEV)
+        zs = wide[:, 3:3 + Cc]
+        ops.bn_apply(xd, scale, shift, resd, True, N, Cc, SP, out=zs)
+        assert rel_err(zs, zr) < 1e-5
+        assert float(wide[:, :3].abs().max()) == 0 and float(wide[:, 3 + Cc:].abs().max()) == 0
+        dwide = torch.zeros_like(wide)
+        dwide[:, 3:3 + Cc] = dz.to(DEV)
+        dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+        dres = torch.empty_like(xd)
+        dx = ops.bn_bwd(dwide[:, 3:3 + Cc], zs, xd, gam, mean, invstd, True, N, Cc, SP, dg, db, dres, False)
+        assert rel_err(dx, xr.grad) < 1e-4
+        assert rel_err(dres, rr.grad) < 1e-5
+        assert rel_err(dg, bn.weight.grad) < 1e-4 and rel_err(db, bn.bias.grad) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['mp133', 'mp333s2', 'mp222', 'mp333s1', 'mp122'])
+def test_maxpool_golden(ops, golden, name):
+    g = golden('ops')
+    cfg = g.t(name + ':cfg').tolist()
+    x = g.t(name + ':x').to(DEV)
+    plan = ops.pool_plan(tuple(x.shape), tuple(cfg[0:3]), tuple(cfg[3:6]), tuple(cfg[6:9]))
+    y, am = ops.maxpool_fwd(plan, x)
+    assert torch.equal(y.cpu(), g.t(name + ':y'))
+    dx = ops.maxpool_bwd(plan, g.t(name + ':dy').to(DEV), am)
+    assert rel_err(dx, g.t(name + ':dx')) < 1e-6        # ties (post-ReLU zeros) must break as ATen does
+
+
+def test_weighted_avgpool(ops):
+    torch.manual_seed(4)
+    x = torch.randn(3, 7, 4, 5, 6)
+    y = ops.wavgpool_fwd(x.to(DEV), None, 1.0 / (4 * 5 * 6))
+    assert rel_err(y, x.mean((2, 3, 4))) < 1e-5
+    # S3D tail: avg_pool3d((2,H,W), stride 1) then mean over T'  (s3d_1.py:30-33)
+    ref = F.avg_pool3d(x, (2, 5, 6), stride=1).flatten(2).mean(2)
+    wt = torch.tensor([1., 2., 2., 1.], device=DEV)
+    y2 = ops.wavgpool_fwd(x.to(DEV), wt, 1.0 / (2 * 30 * 3))
+    assert rel_err(y2, ref) < 1e-5
+    dy = torch.randn(3, 7)
+    dx = ops.wavgpool_bwd(dy.to(DEV), wt, 1.0 / (2 * 30 * 3), tuple(x.shape))
+    xr = x.clone().requires_grad_(True)
+    F.avg_pool3d(xr, (2, 5, 6), stride=1).flatten(2).mean(2).backward(dy)
+    assert rel_err(dx, xr.grad) < 1e-5
+
+
+def test_head_pieces(ops):
+    torch.manual_seed(5)
+    x = torch.randn(6, 40)
+    xr = x.clone().requires_grad_(True)
+    yr = F.normalize(xr, dim=1)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    y, inv = ops.l2norm_fwd(x.to(DEV))
+    assert rel_err(y, yr) < 1e-5
+    assert rel_err(ops.l2norm_bwd(dy.to(DEV), y, inv), xr.grad) < 1e-5
+    r = ops.relu_fwd(x.to(DEV))
+    assert torch.equal(r.cpu(), F.relu(x))
+    assert torch.equal(ops.relu_bwd(dy.to(DEV), r).cpu(), dy * (x > 0))
+    # SimSiam negative cosine
+    p, z = torch.randn(5, 24), torch.randn(5, 24)
+    pr = p.clone().requires_grad_(True)
+    lr = -F.cosine_similarity(pr, z, dim=-1).mean() * 0.5
+    lr.backward()
+    buf = torch.zeros(6, device=DEV)
+    dp = ops.negcos(p.to(DEV), z.to(DEV), 0.5, buf, False)
+    assert rel_err(buf[:1], lr.detach().reshape(1)) < 1e-5 and rel_err(dp, pr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('tag,K,D,steps', [('k8', 8, 16, 5), ('k256', 256, 128, 3)])
+def test_moco_queue_trace_golden(ops, golden, tag, K, D, steps):
+    """RGBMoCo + NCESoftmaxLoss trace incl. ring wrap with n not dividing K (mem_moco.py / criterion.py)."""
+    g = golden('moco')
+    mem = g.t(tag + ':mem0').to(DEV)
+    ptr = 0
+    for s in range(steps):
+        q, k = g.t('%s:q%d' % (tag, s)).to(DEV), g.t('%s:k%d' % (tag, s)).to(DEV)
+        logits, lse, rank = ops.moco_logits_fwd(q, k, mem, 1 / 0.07, want_lse=True, want_rank=True)
+        assert rel_err(logits, g.t('%s:logits%d' % (tag, s))) < 1e-5
+        loss, _ = ops.nce_loss_fwd(logits, lse)
+        assert rel_err(loss, g.t('%s:loss%d' % (tag, s)).reshape(1)) < 1e-5
+        saved = ops.queue_enqueue(mem, k, ptr, save=True)
+        # gradient against the PRE-enqueue snapshot although the rows are already overwritten
+        dq = ops.moco_logits_bwd(k, mem, 1 / 0.07, logits=logits, lse=lse, ov_start=ptr, ov_rows=saved)
+        assert rel_err(dq, g.t('%s:dq%d' % (tag, s))) < 1e-4
+        dl = ops.nce_loss_bwd(logits, lse)
+        dq2 = ops.moco_logits_bwd(k, mem, 1 / 0.07, dlogits=dl, ov_start=ptr, ov_rows=saved)
+        assert rel_err(dq2, dq) < 1e-5
+        ptr = (ptr + q.shape[0]) % K
+        assert torch.equal(mem.cpu(), g.t('%s:mem%d' % (tag, s + 1)))
+        assert ptr == int(g.t('%s:ptr%d' % (tag, s + 1)))
+        prec1 = float((rank < 1).float().mean() * 100)
+        assert abs(prec1 - float(g.t('%s:prec1_%d' % (tag, s)))) < 1e-4
+
+
+def test_moco_allk_wrap_and_device_pointer(ops, golden):
+    g = golden('moco')
+    mem = g.t('allk:mem0').to(DEV)
+    ptr_dev = torch.tensor([6], dtype=torch.long, device=DEV)
+    lg, _, _ = ops.moco_logits_fwd(g.t('allk:q').to(DEV), g.t('allk:k').to(DEV), mem, 1 / 0.07)
+    assert rel_err(lg, g.t('allk:logits')) < 1e-5
+    ops.queue_enqueue(mem, g.t('allk:all_k').to(DEV), 0, ptr_dev=ptr_dev)
+    ops.queue_advance(ptr_dev, 4, 8)
+    assert torch.equal(mem.cpu(), g.t('allk:mem1')) and int(ptr_dev) == 2
+
+
+@pytest.mark.parametrize('b,K', [(32, 4096), (5, 1000), (40, 65536)])
+def test_infonce_sizes_vs_oracle(ops, b, K):
+    """BASELINE configs' InfoNCE shapes (b=32 K=4096 / 65536) + ragged sizes, vs the oracle."""
+    from oracle.moco import RGBMoCo, NCESoftmaxLoss
+    torch.manual_seed(6)
+    D = 128
+    mo = RGBMoCo(D, K=K, T=0.07)
+    q = F.normalize(torch.randn(b, D)).requires_grad_(True)
+    k = F.normalize(torch.randn(b, D))
+    mem0 = mo.memory.clone()
+    logits_r, _ = mo(q, k)
+    loss_r = NCESoftmaxLoss()(logits_r)
+    loss_r.backward()
+    mem = mem0.to(DEV)
+    logits, lse, rank = ops.moco_logits_fwd(q.detach().to(DEV), k.to(DEV), mem, 1 / 0.07, True, True)
+    assert rel_err(logits, logits_r) < 1e-5
+    loss, _ = ops.nce_loss_fwd(logits, lse)
+    assert rel_err(loss, loss_r.detach().reshape(1)) < 1e-5
+    dq = ops.moco_logits_bwd(k.to(DEV), mem, 1 / 0.07, logits=logits, lse=lse)
+    assert rel_err(dq, q.grad) < 1e-4
+    want_rank = (logits_r.detach()[:, 1:] >= logits_r.detach()[:, :1]).sum(1)
+    assert torch.equal(rank.cpu().long(), want_rank)
+
+
+def test_graph_block_golden(ops, golden):
+    """sim adjacency / hop weighting / relaxed-Bernoulli sample / GCN aggregation (temporal_graph.py)."""
+    g = golden('graph')
+    w = g.group('aug:w:')
+    x = g.t('aug:x').to(DEV)
+    wq, wk, wg = (w[n].to(DEV) for n in ('g_q.0.weight', 'g_k.0.weight', 'gcns.0.conv.weight'))
+    pl = ops.conv_plan(tuple(x.shape), wq.shape[0], 1, 1, 0, DEV)
+    pp = ops.pool_plan(pl.out_shape, (1, 2, 2), (1, 2, 2), (0, 0, 0))
+    gq, _ = ops.maxpool_fwd(pp, ops.conv_fwd(pl, x, ops.conv_pack(pl, 0, wq)))
+    gk, _ = ops.maxpool_fwd(pp, ops.conv_fwd(pl, x, ops.conv_pack(pl, 0, wk)))
+    sim, pre, adj = ops.graph_adj_fwd(gq, gk, g.t('aug:u').to(DEV), 3, 0.5, 1.0)
+    assert rel_err(sim, g.t('aug:sim')) < 1e-4
+    assert rel_err(pre, g.t('aug:pre')) < 1e-4
+    assert rel_err(adj, g.t('aug:adj')) < 1e-4
+    pg = ops.conv_plan(tuple(x.shape), wg.shape[0], 1, 1, 0, DEV)
+    s = ops.conv_fwd(pg, x, ops.conv_pack(pg, 0, wg))
+    out = ops.graph_gcn_fwd(g.t('aug:adj').to(DEV), s)
+    assert rel_err(out, g.t('aug:y')) < 1e-5
+
+
+def test_ema_sgd_multitensor(ops):
+    torch.manual_seed(7)
+    n = 256 * 37
+    p, pe, gr = torch.randn(n), torch.randn(n), torch.randn(n)
+    ped = pe.to(DEV)
+    ops.ema_update(ped, p.to(DEV), 0.999)
+    assert rel_err(ped, pe * 0.999 + p * (1 - 0.999)) < 1e-6
+    # SGD with two (lr, wd) classes alternating per chunk, two steps (momentum buffer carry)
+    lr = torch.where(torch.arange(n // 256) % 2 == 0, 0.06, 0.12).float()
+    wd = torch.where(torch.arange(n // 256) % 2 == 0, 5e-4, 0.0).float()
+    pr = p.clone()
+    groups = [{'params': [torch.nn.Parameter(pr[i * 256:(i + 1) * 256].clone())], 'lr': float(lr[i]),
+               'weight_decay': float(wd[i])} for i in range(n // 256)]
+    opt = torch.optim.SGD(groups, momentum=0.9)
+    pd, buf = p.to(DEV), torch.zeros(n, device=DEV)
+    for step in range(2):
+        gstep = gr * (step + 1)
+        for i, gp in enumerate(groups):
+            gp['params'][0].grad = gstep[i * 256:(i + 1) * 256].clone()
+        opt.step()
+        ops.sgd_step(pd, gstep.to(DEV), buf, lr.to(DEV), wd.to(DEV), 1.0, 0.9, False)
+    want = torch.cat([gp['params'][0].data for gp in groups])
+    assert rel_err(pd, want) < 1e-6

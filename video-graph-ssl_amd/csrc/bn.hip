@@ -1,0 +1,290 @@
+// Training-mode BatchNorm (3d / 1d) fused with ReLU and the residual add, gfx950.
+// All of it is HBM-bound streaming: float4 accesses, one pass per tensor, per-channel partial
+// sums finished in fp64 so the batch statistics do not depend on the tile decomposition.
+// Reference call sites: see include/gca_hip.h (BatchNorm section).
+#include "gca_common.h"
+
+namespace {
+
+constexpr int STAT_CHUNK = 8192;     // elements of one channel handled per stats block
+constexpr int MAX_PARTS = 256;
+
+__host__ __device__ inline long long stats_parts(long long N, long long C, long long SP) {
+  long long p = (N * SP + STAT_CHUNK - 1) / STAT_CHUNK;
+  if (p < 1) p = 1;
+  if (p > MAX_PARTS) p = MAX_PARTS;
+  return p;
+}
+
+// grid (P, C): block (part, c) reduces a contiguous slice of channel c's N*SP elements.
+// `f(i_global)` style is avoided: we walk (n, sp) so reads stay contiguous inside a plane.
+template <int MODE>   // 0: sum x, x^2     1: sum dz, dz*xhat (backward)
+__global__ __launch_bounds__(256) void bn_reduce_kernel(
+    const float* __restrict__ a, const float* __restrict__ z, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+    long long N, long long C, long long SP, long long zs, int P, float* __restrict__ out0,
+    float* __restrict__ out1) {
+  __shared__ float sh[4];
+  const int c = blockIdx.y, part = blockIdx.x;
+  const long long M = N * SP;
+  const long long per = (M + P - 1) / P;
+  const long long lo = part * per;
+  long long hi = lo + per; if (hi > M) hi = M;
+  float s0 = 0.f, s1 = 0.f;
+  float mu = 0.f, is = 0.f;
+  if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+  const long long i0 = lo + threadIdx.x;
+  const bool walk = SP >= 256;                      // big planes: one division, then walk incrementally
+  long long n = i0 / SP, sp = i0 - n * SP;
+  for (long long i = i0; i < hi; i += 256, sp += 256) {
+    if (walk) { while (sp >= SP) { sp -= SP; ++n; } }
+    else { n = i / SP; sp = i - n * SP; }
+    const long long idx = (n * C + c) * SP + sp;
+    if (MODE == 0) {
+      const float v = a[idx];
+      s0 += v; s1 += v * v;
+    } else {
+      const long long zidx = n * zs + c * SP + sp;       // dz / z may be channel slices of a concat buffer
+      float dz = a[zidx];
+      if (relu && !(z[zidx] > 0.f)) dz = 0.f;
+      s0 += dz; s1 += dz * ((x[idx] - mu) * is);
+    }
+  }
+  s0 = gca_block_sum256(s0, sh);
+  s1 = gca_block_sum256(s1, sh);
+  if (threadIdx.x == 0) {
+    out0[(long long)c * P + part] = s0;
+    out1[(long long)c * P + part] = s1;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ psum, const float* __restrict__ psq, long long P, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
+    float* __restrict__ sinvstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (long long i = threadIdx.x; i < P; i += 256) { s += (double)psum[c * P + i]; q += (double)psq[c * P + i]; }
+  s = gca_block_sum256_d(s, sh);
+  q = gca_block_sum256_d(q, sh);
+  if (threadIdx.x == 0) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    if (smean) smean[c] = (float)m;
+    if (sinvstd) sinvstd[c] = (float)is;
+    if (rmean) rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * m);
+    if (rvar) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * (float)is;
+    scale[c] = sc;
+    shift[c] = b - (float)m * sc;
+  }
+}
+
+__global__ void bn_counter_kernel(long long* nbt) { if (threadIdx.x == 0 && blockIdx.x == 0) *nbt += 1; }
+
+__global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                    long long C, float* scale, float* shift) {
+  const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.f / sqrtf(rv[c] + eps);
+  const float sc = (gamma ? gamma[c] : 1.f) * is;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rm[c] * sc;
+}
+
+// z = [relu](x*scale[c] + shift[c] [+ res]);  VEC = 4 when SP % 4 == 0 (a float4 never straddles a plane)
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, int relu, long long total, long long C, long long SP, long long zs,
+    float* __restrict__ z) {
+  const long long stride = (long long)gridDim.x * 256 * VEC;
+  const bool small = total < (1LL << 31);           // 32-bit index math (the usual case)
+  const long long zskip = zs - C * SP;              // extra elements between samples of z (concat slice)
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
+    int c; long long n;
+    if (small) { const unsigned q = (unsigned)i / (unsigned)SP; n = q / (unsigned)C; c = (int)(q - (unsigned)n * (unsigned)C); }
+    else { const long long q = i / SP; n = q / C; c = (int)(q - n * C); }
+    const long long zi = i + n * zskip;
+    const float sc = scale[c], sf = shift[c];
+    if (VEC == 4) {
+      float4 v = *reinterpret_cast<const float4*>(x + i);
+      v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
+      if (res) { const float4 r = *reinterpret_cast<const float4*>(res + i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(z + zi) = v;
+    } else {
+      float v = x[i] * sc + sf;
+      if (res) v += res[i];
+      if (relu) v = fmaxf(v, 0.f);
+      z[zi] = v;
+    }
+  }
+}
+
+// per channel: finish the backward sums, write dgamma/dbeta (+=), coefficient triplet for the apply pass
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ p0, const float* __restrict__ p1, int P, double count,
+    const float* __restrict__ gamma, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef /* [3][C] */, long long C) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < P; i += 256) { s0 += (double)p0[(long long)c * P + i]; s1 += (double)p1[(long long)c * P + i]; }
+  s0 = gca_block_sum256_d(s0, sh);
+  s1 = gca_block_sum256_d(s1, sh);
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[c] += (float)s0;
+    if (dgamma) dgamma[c] += (float)s1;
+    const float g = gamma ? gamma[c] : 1.f;
+    coef[c] = g * invstd[c];
+    coef[C + c] = (float)(s0 / count);
+    coef[2 * C + c] = (float)(s1 / count);
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dzin, const float* __restrict__ z, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+    int relu, long long total, long long C, long long SP, long long zs, float* __restrict__ dx,
+    float* __restrict__ dres, int dres_acc) {
+  const long long stride = (long long)gridDim.x * 256 * VEC;
+  const bool small = total < (1LL << 31);           // 32-bit index math (the usual case)
+  const long long zskip = zs - C * SP;
+  for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * VEC; i < total; i += stride) {
+    int c; long long n;
+    if (small) { const unsigned q = (unsigned)i / (unsigned)SP; n = q / (unsigned)C; c = (int)(q - (unsigned)n * (unsigned)C); }
+    else { const long long q = i / SP; n = q / C; c = (int)(q - n * C); }
+    const long long zi = i + n * zskip;
+    const float A = coef[c], B = coef[C + c], Cc = coef[2 * C + c], mu = mean[c], is = invstd[c];
+    if (VEC == 4) {
+      float4 d = *reinterpret_cast<const float4*>(dzin + zi);
+      if (relu) {
+        const float4 zz = *reinterpret_cast<const float4*>(z + zi);
+        if (!(zz.x > 0.f)) d.x = 0.f; if (!(zz.y > 0.f)) d.y = 0.f; if (!(zz.z > 0.f)) d.z = 0.f; if (!(zz.w > 0.f)) d.w = 0.f;
+      }
+      const float4 xv = *reinterpret_cast<const float4*>(x + i);
+      float4 o;
+      o.x = A * (d.x - B - (xv.x - mu) * is * Cc);
+      o.y = A * (d.y - B - (xv.y - mu) * is * Cc);
+      o.z = A * (d.z - B - (xv.z - mu) * is * Cc);
+      o.w = A * (d.w - B - (xv.w - mu) * is * Cc);
+      *reinterpret_cast<float4*>(dx + i) = o;
+      if (dres) {
+        if (dres_acc) { const float4 r = *reinterpret_cast<const float4*>(dres + i); d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
+        *reinterpret_cast<float4*>(dres + i) = d;
+      }
+    } else {
+      float d = dzin[zi];
+      if (relu && !(z[zi] > 0.f)) d = 0.f;
+      dx[i] = A * (d - B - (x[i] - mu) * is * Cc);
+      if (dres) dres[i] = dres_acc ? dres[i] + d : d;
+    }
+  }
+}
+
+inline unsigned ew_grid(long long total, int vec) {
+  long long b = gca_ceil_div(total, 256LL * vec);
+  if (b > 8192) b = 8192;          // grid-stride the rest
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gca_bn_stats_parts(int64_t N, int64_t C, int64_t SP) { return stats_parts(N, C, SP); }
+
+int gca_bn_stats(const float* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
+                 int64_t* parts_out, void* stream) {
+  if (!x || !stat_sum || !stat_sq || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
+  const int P = (int)stats_parts(N, C, SP);
+  if (parts_out) *parts_out = P;
+  hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
+                     nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P, stat_sum,
+                     stat_sq);
+  return gca_launch_status();
+}
+
+int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                    float* save_mean, float* save_invstd, float* scale, float* shift, void* stream) {
+  if (!stat_sum || !stat_sq || P <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GCA_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, stat_sum, stat_sq,
+                     (long long)P, count, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                     save_invstd, scale, shift);
+  if (num_batches_tracked)
+    hipLaunchKernelGGL(bn_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)num_batches_tracked);
+  return gca_launch_status();
+}
+
+int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
+                     const float* running_var, float eps, int64_t C, float* scale, float* shift, void* stream) {
+  if (!running_mean || !running_var || !scale || !shift || C <= 0) return GCA_EINVAL;
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((unsigned)gca_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     gamma, beta, running_mean, running_var, eps, (long long)C, scale, shift);
+  return gca_launch_status();
+}
+
+int gca_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
+                 int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream) {
+  if (!x || !scale || !shift || !z || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+  const long long total = (long long)N * C * SP;
+  const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)x | (uintptr_t)z | (uintptr_t)residual) % 16 == 0);
+  if (v4)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(ew_grid(total, 4)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, residual, relu, total, (long long)C, (long long)SP, zs, z);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(total, 1)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, residual, relu, total, (long long)C, (long long)SP, zs, z);
+  return gca_launch_status();
+}
+
+int64_t gca_bn_bwd_ws_bytes(int64_t N, int64_t C, int64_t SP) {
+  if (N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
+  return (int64_t)sizeof(float) * (2 * C * stats_parts(N, C, SP) + 3 * C);
+}
+
+int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* gamma,
+               const float* save_mean, const float* save_invstd, int relu,
+               int64_t N, int64_t C, int64_t SP, float* dx, float* dgamma, float* dbeta,
+               float* dres, int dres_accumulate, int64_t z_batch_stride, void* ws, void* stream) {
+  if (!dz_in || !x || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
+  if (relu && !z) return GCA_EINVAL;
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+  hipStream_t st = (hipStream_t)stream;
+  const int P = (int)stats_parts(N, C, SP);
+  float* p0 = reinterpret_cast<float*>(ws);
+  float* p1 = p0 + (long long)C * P;
+  float* coef = p1 + (long long)C * P;
+  hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
+                     save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, p0, p1, P, (double)N * (double)SP,
+                     gamma, save_invstd, dgamma, dbeta, coef, (long long)C);
+  const long long total = (long long)N * C * SP;
+  const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) &&
+                  (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
+  if (v4)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_grid(total, 4)), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_grid(total, 1)), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate);
+  return gca_launch_status();
+}
+
+}  // extern "C"

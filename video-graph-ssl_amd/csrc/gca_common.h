@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels of libgca_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gca_hip.h"
+
+#define GCA_WAVE 64
+
+static inline int gca_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? GCA_OK : GCA_ELAUNCH;
+}
+
+static inline int64_t gca_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int64_t gca_round_up(int64_t a, int64_t b) { return gca_ceil_div(a, b) * b; }
+
+// XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are
+// consecutive end up on the same XCD, so tiles sharing an operand panel share an L2.
+// Bijective for any grid size.  Speed only, never correctness.
+__device__ __forceinline__ int gca_xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ float gca_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double gca_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float gca_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread.
+__device__ __forceinline__ float gca_block_sum256(float v, float* sh /* >= 4 floats */) {
+  v = gca_wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ double gca_block_sum256_d(double v, double* sh) {
+  v = gca_wave_sum_d(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}

@@ -1,0 +1,319 @@
+// MoCo queue + InfoNCE on gfx950.
+//
+//   logits[i,0]   = q_i . k_i / T
+//   logits[i,1+j] = q_i . queue_j / T          one batched clip x queue GEMM on the fp32 matrix cores,
+//                                              streaming the (K,D) queue from HBM exactly once
+//   loss          = mean_i ( logsumexp(logits_i) - logits[i,0] )
+//   dq            = ( dlogits[:,0] * k + dlogits[:,1:] @ queue ) / T     split over queue slices
+//
+// HBM-bound (AI ~ 12.7 F/B at b=32): algorithmic bytes = K*D*4 (queue) + b*(K+1)*4 (logits).
+// Reference: lib/memory/mem_moco.py:14-49,60-88; lib/memory/criterion.py:34-45.
+#include "gca_common.h"
+#include <math.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int DCH = 64;              // feature chunk staged per pass
+constexpr int QLD = DCH + 4;         // LDS row stride of the staged queue tile (float4-aligned)
+
+// One wave = 32 queue rows x all batch rows (in tiles of 32).  WAVES waves per workgroup share
+// the staged q tile.  MFMA orientation: A = q (M = batch rows), B = queue^T (N = queue rows), so
+// the 32 lanes of a half-wave hold 32 consecutive logits of one batch row -> coalesced stores.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void moco_logits_kernel(
+    const float* __restrict__ q, const float* __restrict__ kpos, const float* __restrict__ queue,
+    int b, long long K, int D, float inv_T, float* __restrict__ logits) {
+  __shared__ float Qs[DCH][32];                  // q tile, k-major: A operand reads are row-contiguous
+  __shared__ float Ns[WAVES][32][QLD];           // per-wave queue tile [row][feature]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lh = lane >> 5, ll = lane & 31;
+  const long long row0 = ((long long)blockIdx.x * WAVES + wave) * 32;
+  const long long ld = K + 1;
+  const int mtiles = (b + 31) / 32;
+
+  for (int mt = 0; mt < mtiles; ++mt) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int d0 = 0; d0 < D; d0 += DCH) {
+      __syncthreads();
+      // stage q[mt*32 .. +32][d0 .. d0+DCH) transposed
+      for (int i = tid; i < 32 * DCH; i += WAVES * 64) {
+        const int m = i / DCH, kk = i % DCH;
+        const int row = mt * 32 + m;
+        Qs[kk][m] = (row < b && d0 + kk < D) ? q[(long long)row * D + d0 + kk] : 0.f;
+      }
+      // stage this wave's 32 queue rows: lanes along the feature axis (coalesced float4)
+      for (int i = lane; i < 32 * (DCH / 4); i += 64) {
+        const int r = i / (DCH / 4), c4 = i % (DCH / 4);
+        const long long row = row0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < K && d0 + c4 * 4 < D) v = *reinterpret_cast<const float4*>(queue + row * D + d0 + c4 * 4);
+        *reinterpret_cast<float4*>(&Ns[wave][r][c4 * 4]) = v;
+      }
+      __syncthreads();
+#pragma unroll 8
+      for (int kk = 0; kk < DCH; kk += 2) {
+        const float a = Qs[kk + lh][ll];
+        const float bb = Ns[wave][ll][kk + lh];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb, acc, 0, 0, 0);
+      }
+    }
+    const long long j = row0 + ll;
+    if (j < K) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (i < b) logits[(long long)i * ld + 1 + j] = acc[r] * inv_T;
+      }
+    }
+  }
+  // positive column: block 0 does the b row dots (wave per row)
+  if (blockIdx.x == 0) {
+    for (int i = wave; i < b; i += WAVES) {
+      float s = 0.f;
+      for (int d = lane; d < D; d += 64) s += q[(long long)i * D + d] * kpos[(long long)i * D + d];
+      s = gca_wave_sum(s);
+      if (lane == 0) logits[(long long)i * ld] = s * inv_T;
+    }
+  }
+}
+
+// One workgroup per batch row: lse_i = logsumexp(logits_i), rank_i = #{j>=1 : l_ij >= l_i0}
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ logits, long long ncol,
+                                                        float* __restrict__ lse, int* __restrict__ rank) {
+  __shared__ float sh[4];
+  __shared__ float shm[4];
+  const float* row = logits + (long long)blockIdx.x * ncol;
+  float m = -INFINITY;
+  for (long long j = threadIdx.x; j < ncol; j += 256) m = fmaxf(m, row[j]);
+  m = gca_wave_max(m);
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  const float l0 = row[0];
+  float s = 0.f, c = 0.f;
+  for (long long j = threadIdx.x; j < ncol; j += 256) {
+    const float v = row[j];
+    s += expf(v - m);
+    if (j >= 1 && v >= l0) c += 1.f;
+  }
+  s = gca_block_sum256(s, sh);
+  c = gca_block_sum256(c, sh);
+  if (threadIdx.x == 0) {
+    if (lse) lse[blockIdx.x] = m + logf(s);
+    if (rank) rank[blockIdx.x] = (int)c;
+  }
+}
+
+__global__ __launch_bounds__(256) void nce_loss_finish_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                              int b, long long ncol, float* __restrict__ loss) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < b; i += 256) s += lse[i] - logits[(long long)i * ncol];
+  s = gca_block_sum256(s, sh);
+  if (threadIdx.x == 0) *loss = s / (float)b;
+}
+
+__global__ __launch_bounds__(256) void nce_loss_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                           int b, long long ncol, const float* __restrict__ gs_dev,
+                                                           float gs_host, float* __restrict__ dl) {
+  const float g = (gs_dev ? *gs_dev : 1.f) * gs_host / (float)b;
+  const long long total = (long long)b * ncol;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long r = i / ncol, j = i - r * ncol;
+    float v = expf(logits[i] - lse[r]);
+    if (j == 0) v -= 1.f;
+    dl[i] = g * v;
+  }
+}
+
+// dq partial over a slice of RS queue rows: slab[slice][i][d] = sum_{j in slice} g[i,1+j] * queue[j,d]
+// grid (slices, D/128, b/32); 4 waves = 4 x 32 feature columns.
+constexpr int BWD_RS = 128;
+__global__ __launch_bounds__(256) void moco_dq_kernel(
+    const float* __restrict__ dl, const float* __restrict__ logits, const float* __restrict__ lse,
+    const float* __restrict__ gs_dev, float gs_host, const float* __restrict__ queue, int b, long long K, int D,
+    long long ov_start, const long long* __restrict__ ov_start_dev, long long ov_n,
+    const float* __restrict__ ov_rows, float* __restrict__ slab) {
+  __shared__ float Gs[BWD_RS][33];
+  if (ov_start_dev) ov_start = *ov_start_dev;      // device-resident queue pointer (graph replay)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lh = lane >> 5, ll = lane & 31;
+  const long long j0 = (long long)blockIdx.x * BWD_RS;
+  const int dcol = blockIdx.y * 128 + wave * 32 + ll;
+  const int mt = blockIdx.z;
+  const long long ld = K + 1;
+  const float g = (gs_dev ? *gs_dev : 1.f) * gs_host / (float)b;
+  // stage G^T: lanes along j (coalesced), one batch row per step
+  for (int i = tid; i < 32 * BWD_RS; i += 256) {
+    const int m = i / BWD_RS, jj = i % BWD_RS;
+    const int row = mt * 32 + m;
+    const long long j = j0 + jj;
+    float v = 0.f;
+    if (row < b && j < K) {
+      if (dl) v = dl[(long long)row * ld + 1 + j];
+      else v = g * expf(logits[(long long)row * ld + 1 + j] - lse[row]);
+    }
+    Gs[jj][m] = v;
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool dv = dcol < D;
+#pragma unroll 4
+  for (int kk = 0; kk < BWD_RS; kk += 2) {
+    const long long j = j0 + kk + lh;
+    float bb = 0.f;
+    if (dv && j < K) {
+      long long rel = j - ov_start; if (rel < 0) rel += K;
+      bb = (rel < ov_n) ? ov_rows[rel * D + dcol] : queue[j * D + dcol];
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[kk + lh][ll], bb, acc, 0, 0, 0);
+  }
+  if (dv) {
+    float* out = slab + (long long)blockIdx.x * b * D;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (i < b) out[(long long)i * D + dcol] = acc[r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void moco_dq_finish_kernel(
+    const float* __restrict__ slab, int slices, const float* __restrict__ dl, const float* __restrict__ logits,
+    const float* __restrict__ lse, const float* __restrict__ gs_dev, float gs_host, const float* __restrict__ kpos,
+    int b, long long K, int D, float inv_T, float* __restrict__ dq) {
+  const long long total = (long long)b * D;
+  const long long ld = K + 1;
+  const float g = (gs_dev ? *gs_dev : 1.f) * gs_host / (float)b;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i = e / D;
+    float s = 0.f;
+    for (int k = 0; k < slices; ++k) s += slab[(long long)k * total + e];
+    float g0;
+    if (dl) g0 = dl[i * ld];
+    else g0 = g * (expf(logits[i * ld] - lse[i]) - 1.f);
+    dq[e] = (s + g0 * kpos[e]) * inv_T;
+  }
+}
+
+__global__ __launch_bounds__(256) void enqueue_kernel(float* __restrict__ queue, long long K, int D,
+                                                      const float* __restrict__ keys, long long n, long long ptr,
+                                                      const long long* __restrict__ ptr_dev,
+                                                      float* __restrict__ saved) {
+  if (ptr_dev) ptr = *ptr_dev;                     // device-resident queue pointer (graph replay)
+  const long long total = n * D;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long i = e / D, d = e - i * D;
+    const long long row = (ptr + i) % K;
+    if (saved) saved[e] = queue[row * D + d];
+    queue[row * D + d] = keys[e];
+  }
+}
+
+__global__ void queue_advance_kernel(long long* ptr_dev, long long n, long long K) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *ptr_dev = (*ptr_dev + n) % K;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t gca_infonce_ws_bytes(int64_t b, int64_t K) {
+  if (b <= 0 || K <= 0) return GCA_EINVAL;
+  // dq partial slabs: one (b x D) slab per BWD_RS-row queue slice, sized for the D <= 256 the
+  // backward kernel accepts.
+  return (int64_t)sizeof(float) * gca_ceil_div(K, BWD_RS) * b * 256;
+}
+
+int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
+                        int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge,
+                        void* ws, void* stream) {
+  (void)ws;
+  if (!q || !k || !queue || !logits || b <= 0 || K <= 0 || D <= 0 || (D & 3)) return GCA_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (K >= 32768)
+    hipLaunchKernelGGL((moco_logits_kernel<4>), dim3((unsigned)gca_ceil_div(K, 128)), dim3(256), 0, st, q, k, queue,
+                       (int)b, (long long)K, (int)D, inv_T, logits);
+  else
+    hipLaunchKernelGGL((moco_logits_kernel<1>), dim3((unsigned)gca_ceil_div(K, 32)), dim3(64), 0, st, q, k, queue,
+                       (int)b, (long long)K, (int)D, inv_T, logits);
+  int rc = gca_launch_status();
+  if (rc) return rc;
+  if (row_lse || rank_ge) {
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, (long long)(K + 1), row_lse, rank_ge);
+    rc = gca_launch_status();
+  }
+  return rc;
+}
+
+int gca_nce_softmax_loss_fwd(const float* logits, int64_t b, int64_t ncol, const float* row_lse_in,
+                             float* row_lse_out, float* loss, void* stream) {
+  if (!logits || !loss || b <= 0 || ncol <= 0) return GCA_EINVAL;
+  if (!row_lse_in && !row_lse_out) return GCA_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const float* lse = row_lse_in;
+  if (!lse) {
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, (long long)ncol, row_lse_out,
+                       (int*)nullptr);
+    lse = row_lse_out;
+  }
+  hipLaunchKernelGGL(nce_loss_finish_kernel, dim3(1), dim3(256), 0, st, logits, lse, (int)b, (long long)ncol, loss);
+  return gca_launch_status();
+}
+
+int gca_nce_softmax_loss_bwd(const float* logits, const float* row_lse, int64_t b, int64_t ncol,
+                             const float* gscale_dev, float gscale_host, float* dlogits, void* stream) {
+  if (!logits || !row_lse || !dlogits || b <= 0 || ncol <= 0) return GCA_EINVAL;
+  long long blocks = gca_ceil_div(b * ncol, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(nce_loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, logits, row_lse,
+                     (int)b, (long long)ncol, gscale_dev, gscale_host, dlogits);
+  return gca_launch_status();
+}
+
+int gca_moco_logits_bwd(const float* dlogits, const float* logits, const float* row_lse,
+                        const float* gscale_dev, float gscale_host,
+                        const float* k, const float* queue, int64_t b, int64_t K, int64_t D, float inv_T,
+                        int64_t ov_start, const int64_t* ov_start_dev, int64_t ov_n, const float* ov_rows,
+                        float* dq, void* ws, void* stream) {
+  if (!k || !queue || !dq || !ws || b <= 0 || K <= 0 || D <= 0 || D > 256) return GCA_EINVAL;
+  if (!dlogits && (!logits || !row_lse)) return GCA_EINVAL;
+  if (ov_n < 0 || ov_n > K || (ov_n > 0 && !ov_rows) || ov_start < 0 || ov_start >= K) return GCA_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int slices = (int)gca_ceil_div(K, BWD_RS);
+  float* slab = reinterpret_cast<float*>(ws);
+  dim3 grid((unsigned)slices, (unsigned)gca_ceil_div(D, 128), (unsigned)gca_ceil_div(b, 32));
+  hipLaunchKernelGGL(moco_dq_kernel, grid, dim3(256), 0, st, dlogits, logits, row_lse, gscale_dev, gscale_host, queue,
+                     (int)b, (long long)K, (int)D, (long long)ov_start, (const long long*)ov_start_dev, (long long)ov_n, ov_rows,
+                     slab);
+  int rc = gca_launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(moco_dq_finish_kernel, dim3((unsigned)gca_ceil_div(b * D, 256)), dim3(256), 0, st, slab, slices,
+                     dlogits, logits, row_lse, gscale_dev, gscale_host, k, (int)b, (long long)K, (int)D, inv_T, dq);
+  return gca_launch_status();
+}
+
+int gca_queue_enqueue(float* queue, int64_t K, int64_t D, const float* keys, int64_t n, int64_t ptr,
+                      const int64_t* ptr_dev, float* saved_rows, void* stream) {
+  if (!queue || !keys || K <= 0 || D <= 0 || n <= 0 || n > K || ptr < 0 || ptr >= K) return GCA_EINVAL;
+  long long blocks = gca_ceil_div(n * D, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(enqueue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, queue, (long long)K,
+                     (int)D, keys, (long long)n, (long long)ptr, (const long long*)ptr_dev, saved_rows);
+  return gca_launch_status();
+}
+
+int gca_queue_advance(int64_t* ptr_dev, int64_t n, int64_t K, void* stream) {
+  if (!ptr_dev || n < 0 || K <= 0) return GCA_EINVAL;
+  hipLaunchKernelGGL(queue_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)ptr_dev, (long long)n,
+                     (long long)K);
+  return gca_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,326 @@
+"""Leaf modules (same parameter/buffer names as torch.nn so reference checkpoints load by key)
+and the fused functional units the encoders are written in.
+
+Every ``f_*`` function takes the tape + Vars, launches HIP kernels for the forward and records
+ONE closure for the backward.  Parameter gradients are accumulated (+=) straight into
+``param.grad`` (views of the flat gradient arena, engine/arena.py).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .tape import Var
+
+
+def _grad_of(p):
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad
+
+
+# ----------------------------------------------------------------------------- leaf modules
+class HipConv3d(nn.Module):
+    """nn.Conv3d(bias=False|True) parameters; default init = torch's (kaiming_uniform a=sqrt 5)."""
+
+    def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=False):
+        super().__init__()
+        t3 = lambda v: (v, v, v) if isinstance(v, int) else tuple(v)
+        self.in_channels, self.out_channels = cin, cout
+        self.kernel_size, self.stride, self.padding = t3(kernel_size), t3(stride), t3(padding)
+        self.weight = nn.Parameter(torch.empty(cout, cin, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(cin * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2])
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._pack = [None, None]
+
+    def plan(self, x):
+        xs = 0
+        if not x.is_contiguous():
+            N, Cc, D, Hh, W = x.shape
+            if x.stride()[1:] != (D * Hh * W, Hh * W, W, 1):
+                raise RuntimeError('conv input must be NCDHW-contiguous inside each clip')
+            xs = x.stride(0)
+        return ops.conv_plan(tuple(x.shape), self.out_channels, self.kernel_size, self.stride, self.padding,
+                             x.device, xs)
+
+    def packed(self, plan, which):
+        self._pack[which] = ops.conv_pack(plan, which, self.weight.data, self._pack[which])
+        return self._pack[which]
+
+    def forward(self, x):      # plain inference use of the leaf (no BN fusion)
+        return ops.conv_fwd(self.plan(x), x, self.packed(self.plan(x), 0), None if self.bias is None else self.bias.data)
+
+
+class _HipBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer('running_mean', torch.zeros(num_features))
+        self.register_buffer('running_var', torch.ones(num_features))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+
+
+class HipBatchNorm3d(_HipBatchNorm):
+    pass
+
+
+class HipBatchNorm1d(_HipBatchNorm):
+    pass
+
+
+class HipLinear(nn.Module):
+    def __init__(self, fin, fout, bias=True):
+        super().__init__()
+        self.in_features, self.out_features = fin, fout
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout)) if bias else None
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if bias:
+            bound = 1 / math.sqrt(fin)
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._pack = [None, None]
+
+    def plan(self, b, device):
+        return ops.conv_plan((b, self.in_features, 1, 1, 1), self.out_features, 1, 1, 0, device)
+
+    def packed(self, plan, which):
+        self._pack[which] = ops.conv_pack(plan, which, self.weight.data, self._pack[which])
+        return self._pack[which]
+
+
+class HipMaxPool3d(nn.Module):
+    def __init__(self, kernel_size, stride=None, padding=0):
+        super().__init__()
+        t3 = lambda v: (v, v, v) if isinstance(v, int) else tuple(v)
+        self.kernel_size = t3(kernel_size)
+        self.stride = t3(stride if stride is not None else kernel_size)
+        self.padding = t3(padding)
+
+
+class HipReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+
+
+class HipIdentity(nn.Module):
+    pass
+
+
+class HipNormalize(nn.Module):
+    def __init__(self, p=2):
+        super().__init__()
+        self.p = p
+
+
+# ----------------------------------------------------------------------------- fused functional units
+def _bn_scale_shift(bn, ss, sq, count):
+    return ops.bn_finalize(ss, sq, count, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,
+                           bn.running_mean, bn.running_var, bn.num_batches_tracked)
+
+
+def f_seq(tape, module, xv):
+    """Run a container: modules with their own ``fwd`` (blocks, graph-wrapped modules), max pools and
+    plain nn.Sequential chains of those."""
+    if hasattr(module, 'fwd'):
+        return module.fwd(tape, xv)
+    if isinstance(module, HipMaxPool3d):
+        return f_maxpool(tape, module, xv)
+    if isinstance(module, nn.Sequential):
+        for m in module:
+            xv = f_seq(tape, m, xv)
+        return xv
+    raise TypeError('engine cannot run %r' % type(module))
+
+
+def f_concat(tape, buf, branch_vars, offsets):
+    """Channel concat without a copy: the branches already wrote their outputs into channel slices of
+    `buf` (f_conv_bn_act(out=...)); on the way back each branch reads its slice of d(buf)."""
+    outv = Var(buf, tape.recording)
+
+    def back():
+        g = outv.grad
+        for bv, off in zip(branch_vars, offsets):
+            bv.grad = g[:, off:off + bv.t.shape[1]]
+        outv.grad = None
+    tape.record(back)
+    return outv
+
+
+def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
+    """z = [relu]( BN(conv(x)) [+ residual] ).  Training-mode BN takes its batch statistics from the
+    conv epilogue (no extra pass over y).  Follows resnet2p1d.py:66-85 / s3d_1.py:43-47,61-68.
+    `out`: optional channel-slice view of a wider buffer to receive z (Inception concat)."""
+    x = xv.t
+    plan = conv.plan(x)
+    N, K, OD, OH, OW = plan.out_shape
+    SP = OD * OH * OW
+    wp = conv.packed(plan, 0)
+    train = bn.training
+    if train:
+        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True)
+        mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
+    else:
+        y = ops.conv_fwd(plan, x, wp, None)
+        mean = invstd = None
+        scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
+    z = ops.bn_apply(y, scale, shift, None if residual is None else residual.t, relu, N, K, SP, out=out)
+    zv = Var(z, tape.recording)
+    if tape.recording:
+        if not train:
+            raise NotImplementedError('backward through eval-mode BatchNorm is not on the pre-training path')
+
+        def back():
+            dres = racc = None
+            if residual is not None and residual.needs_grad:
+                dres, racc = residual.grad_buffer()
+            dy = ops.bn_bwd(zv.grad, z, y, bn.weight.data, mean, invstd, relu, N, K, SP,
+                            _grad_of(bn.weight), _grad_of(bn.bias), dres, bool(racc))
+            zv.grad = None
+            ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
+            if xv.needs_grad:
+                buf, acc = xv.grad_buffer()
+                ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
+        tape.record(back)
+    return zv
+
+
+def f_conv(tape, conv, xv):
+    """Plain convolution (optional bias), no normalisation: temporal_graph.py:46,119-122."""
+    x = xv.t
+    plan = conv.plan(x)
+    y = ops.conv_fwd(plan, x, conv.packed(plan, 0), None if conv.bias is None else conv.bias.data)
+    yv = Var(y, tape.recording)
+
+    def back():
+        dy = yv.grad
+        yv.grad = None
+        ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
+        if conv.bias is not None:
+            N, K, OD, OH, OW = plan.out_shape
+            ops.bias_grad(dy, N, K, OD * OH * OW, _grad_of(conv.bias), True)
+        if xv.needs_grad:
+            buf, acc = xv.grad_buffer()
+            ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
+    tape.record(back)
+    return yv
+
+
+def f_linear(tape, lin, xv):
+    """y = x W^T + b through the conv kernels as a 1x1x1 conv on (b, C, 1, 1, 1)."""
+    x = xv.t
+    b = x.shape[0]
+    plan = lin.plan(b, x.device)
+    y = ops.conv_fwd(plan, x, lin.packed(plan, 0), None if lin.bias is None else lin.bias.data).view(b, lin.out_features)
+    yv = Var(y, tape.recording)
+
+    def back():
+        dy = yv.grad
+        yv.grad = None
+        ops.conv_wgrad(plan, x, dy, _grad_of(lin.weight), accumulate=True)
+        if lin.bias is not None:
+            ops.bias_grad(dy, b, lin.out_features, 1, _grad_of(lin.bias), True)
+        if xv.needs_grad:
+            buf, acc = xv.grad_buffer()
+            ops.conv_dgrad(plan, dy, lin.packed(plan, 1), buf, acc)
+    tape.record(back)
+    return yv
+
+
+def f_bn1d_act(tape, bn, xv, relu):
+    """BatchNorm1d (+ReLU) on (b, C): project_head.py:39-50,64-68."""
+    x = xv.t
+    b, Cc = x.shape
+    if bn.training:
+        ss, sq = ops.bn_stats(x, b, Cc, 1)
+        mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, b)
+    else:
+        mean = invstd = None
+        scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
+    z = ops.bn_apply(x, scale, shift, None, relu, b, Cc, 1)
+    zv = Var(z, tape.recording)
+
+    def back():
+        if mean is None:
+            raise NotImplementedError('backward through eval-mode BatchNorm1d')
+        dx = ops.bn_bwd(zv.grad, z, x, bn.weight.data, mean, invstd, relu, b, Cc, 1,
+                        _grad_of(bn.weight), _grad_of(bn.bias))
+        zv.grad = None
+        if xv.needs_grad:
+            xv.add_grad(dx)
+    tape.record(back)
+    return zv
+
+
+def f_relu(tape, xv):
+    y = ops.relu_fwd(xv.t)
+    yv = Var(y, tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            xv.add_grad(ops.relu_bwd(yv.grad, y))
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
+def f_maxpool(tape, pool, xv):
+    x = xv.t
+    plan = ops.pool_plan(tuple(x.shape), pool.kernel_size, pool.stride, pool.padding)
+    y, am = ops.maxpool_fwd(plan, x, want_argmax=tape.recording and xv.needs_grad)
+    yv = Var(y, tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            buf, acc = xv.grad_buffer()
+            ops.maxpool_bwd(plan, yv.grad, am, buf, acc)
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
+def f_wavgpool(tape, xv, wt=None, norm=None):
+    """(N,C,D,H,W) -> (N,C): norm * sum_d wt[d] * sum_hw x.  Global mean when wt is None."""
+    x = xv.t
+    if norm is None:
+        norm = 1.0 / (x.shape[2] * x.shape[3] * x.shape[4])
+    y = ops.wavgpool_fwd(x, wt, norm)
+    yv = Var(y, tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            xv.add_grad(ops.wavgpool_bwd(yv.grad, wt, norm, tuple(x.shape)))
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
+def f_l2norm(tape, xv):
+    y, inv = ops.l2norm_fwd(xv.t)
+    yv = Var(y, tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            xv.add_grad(ops.l2norm_bwd(yv.grad, y, inv))
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
+def f_head_fc(tape, fc, xv):
+    """The backbone's last layer after VisualModelWrapper replaced it (visual_wrappers.py:107-110):
+    Identity for DROPOUT == 0, otherwise whatever was left there."""
+    if isinstance(fc, HipIdentity):
+        return xv
+    if isinstance(fc, HipLinear):
+        return f_linear(tape, fc, xv)
+    if isinstance(fc, nn.Dropout):
+        if fc.p == 0 or not fc.training:
+            return xv
+        raise NotImplementedError('dropout > 0 is not used by the pre-training configs (DROPOUT: 0.)')
+    raise TypeError('unsupported head module %r' % type(fc))

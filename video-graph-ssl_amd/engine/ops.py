@@ -1,0 +1,376 @@
+"""Thin tensor-level wrappers over the C ABI (one function per kernel family).
+
+torch is used for device memory and the current HIP stream only; every arithmetic
+operation below runs in libgca_hip.so.  Geometry-dependent host data (gather tables,
+workspace sizes) is cached per geometry.
+"""
+import ctypes as C
+import functools
+
+import torch
+
+from .. import _hip as H
+from .._hip import ptr, stream
+
+F32 = torch.float32
+
+
+def _t3(v):
+    return (v, v, v) if isinstance(v, int) else tuple(int(a) for a in v)
+
+
+# ----------------------------------------------------------------------------- workspace
+class _Workspace:
+    """One grow-only scratch buffer per device.  All kernels run stream-ordered on the current
+    stream, so consecutive users never overlap in time."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        key = (device.type, device.index)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('workspace would grow during graph capture; run one eager step first')
+            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b
+
+
+WS = _Workspace()
+
+
+# ----------------------------------------------------------------------------- convolution
+class ConvPlan:
+    """Everything geometry-dependent about one conv: the ABI struct, device gather tables."""
+
+    def __init__(self, N, Cin, D, Hh, W, K, k, s, p, device, x_batch_stride=0):
+        kd, kh, kw = _t3(k)
+        sd, sh, sw = _t3(s)
+        pd, ph, pw = _t3(p)
+        OD, OH, OW = (D + 2 * pd - kd) // sd + 1, (Hh + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        self.g = H.ConvGeom(N, Cin, D, Hh, W, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, OD, OH, OW, x_batch_stride)
+        self.gp = C.byref(self.g)
+        self.in_shape = (N, Cin, D, Hh, W)
+        self.out_shape = (N, K, OD, OH, OW)
+        self.device = device
+        self._tables = {}
+        self.parts = H.lib.gca_conv_fwd_stat_parts(self.gp)
+        if self.parts < 0:
+            raise ValueError('unsupported conv geometry %r' % ((N, Cin, D, Hh, W, K, k, s, p),))
+        self.pack_elems = [H.lib.gca_conv_pack_elems(self.gp, 0), H.lib.gca_conv_pack_elems(self.gp, 1)]
+        self.wgrad_ws = H.lib.gca_conv_wgrad_ws_bytes(self.gp)
+
+    def table(self, which):
+        t = self._tables.get(which)
+        if t is None:
+            rows = H.lib.gca_conv_table_rows(self.gp, which)
+            host = torch.empty(rows * 2, dtype=torch.int32)
+            H.call('gca_conv_table_build_host', self.gp, which, host.data_ptr())
+            t = host.to(self.device)
+            self._tables[which] = t
+        return t
+
+
+@functools.lru_cache(maxsize=None)
+def _conv_plan(N, Cin, D, Hh, W, K, k, s, p, dev_type, dev_index, xbs):
+    return ConvPlan(N, Cin, D, Hh, W, K, k, s, p, torch.device(dev_type, dev_index), xbs)
+
+
+def conv_plan(x_shape, K, k, s, p, device, x_batch_stride=0):
+    N, Cin, D, Hh, W = x_shape
+    return _conv_plan(N, Cin, D, Hh, W, K, _t3(k), _t3(s), _t3(p), device.type, device.index, int(x_batch_stride))
+
+
+def conv_pack(plan, which, w, out=None):
+    n = plan.pack_elems[which]
+    if out is None or out.numel() != n:
+        out = torch.empty(n, dtype=F32, device=w.device)
+    H.call('gca_conv_pack', plan.gp, which, ptr(w), ptr(out), stream())
+    return out
+
+
+def conv_fwd(plan, x, wpack, bias=None, stats=False):
+    """-> y [, (stat_sum, stat_sq)]  with stat layout [K][plan.parts]."""
+    y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    ss = sq = None
+    if stats:
+        ss = torch.empty((plan.g.K, plan.parts), dtype=F32, device=x.device)
+        sq = torch.empty((plan.g.K, plan.parts), dtype=F32, device=x.device)
+    H.call('gca_conv_fwd', plan.gp, ptr(x), ptr(wpack), ptr(plan.table(0)), ptr(bias), ptr(y), ptr(ss), ptr(sq),
+           stream())
+    return (y, (ss, sq)) if stats else y
+
+
+def conv_dgrad(plan, dy, wpack_t, dx=None, accumulate=False):
+    if dx is None:
+        dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        accumulate = False
+    H.call('gca_conv_dgrad', plan.gp, ptr(dy), ptr(wpack_t), ptr(plan.table(1)), ptr(dx), int(accumulate), stream())
+    return dx
+
+
+def conv_wgrad(plan, x, dy, dw, accumulate=True):
+    ws = WS.get(plan.wgrad_ws, x.device)
+    H.call('gca_conv_wgrad', plan.gp, ptr(x), ptr(dy), ptr(plan.table(2)), ptr(dw), int(accumulate), ptr(ws), stream())
+    return dw
+
+
+def bias_grad(dy, N, K, SP, db, accumulate=True):
+    H.call('gca_bias_grad', ptr(dy), N, K, SP, ptr(db), int(accumulate), stream())
+
+
+# ----------------------------------------------------------------------------- batch norm
+def bn_stats(x, N, Cc, SP):
+    P = H.lib.gca_bn_stats_parts(N, Cc, SP)
+    ss = torch.empty((Cc, P), dtype=F32, device=x.device)
+    sq = torch.empty((Cc, P), dtype=F32, device=x.device)
+    H.call('gca_bn_stats', ptr(x), N, Cc, SP, ptr(ss), ptr(sq), None, stream())
+    return ss, sq
+
+
+def bn_finalize(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt):
+    """-> (save_mean, save_invstd, scale, shift); running stats updated in place."""
+    Cc, P = ss.shape
+    out = torch.empty((4, Cc), dtype=F32, device=ss.device)
+    H.call('gca_bn_finalize', ptr(ss), ptr(sq), P, Cc, float(count), ptr(gamma), ptr(beta), float(eps),
+           float(momentum), ptr(rmean), ptr(rvar), ptr(nbt), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
+           stream())
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_fold_eval(gamma, beta, rmean, rvar, eps):
+    Cc = rmean.numel()
+    out = torch.empty((2, Cc), dtype=F32, device=rmean.device)
+    H.call('gca_bn_fold_eval', ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(eps), Cc, ptr(out[0]), ptr(out[1]),
+           stream())
+    return out[0], out[1]
+
+
+def _slice_stride(t, Cc, SP):
+    """0 for a contiguous (N,C,...) tensor, else the batch stride of a channel-slice view."""
+    if t.is_contiguous():
+        return 0
+    if t.dim() < 2 or t[0].is_contiguous() is False:
+        raise RuntimeError('only channel slices of a contiguous (N, Ctot, ...) buffer are supported')
+    return t.stride(0)
+
+
+def bn_apply(x, scale, shift, residual, relu, N, Cc, SP, out=None):
+    z = torch.empty_like(x) if out is None else out
+    H.call('gca_bn_apply', ptr(x), ptr(scale), ptr(shift), ptr(residual), int(relu), N, Cc, SP, ptr(z),
+           _slice_stride(z, Cc, SP), stream())
+    return z
+
+
+def bn_bwd(dz, z, x, gamma, mean, invstd, relu, N, Cc, SP, dgamma, dbeta, dres=None, dres_accumulate=False):
+    dx = torch.empty_like(x)
+    ws = WS.get(H.lib.gca_bn_bwd_ws_bytes(N, Cc, SP), x.device)
+    H.call('gca_bn_bwd', ptr(dz), ptr(z), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu), N, Cc, SP, ptr(dx),
+           ptr(dgamma), ptr(dbeta), ptr(dres), int(dres_accumulate), _slice_stride(dz, Cc, SP), ptr(ws), stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------- pooling
+class PoolPlan:
+    def __init__(self, x_shape, k, s, p):
+        N, Cc, D, Hh, W = x_shape
+        kd, kh, kw = _t3(k)
+        sd, sh, sw = _t3(s)
+        pd, ph, pw = _t3(p)
+        OD, OH, OW = (D + 2 * pd - kd) // sd + 1, (Hh + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        self.g = H.PoolGeom(N, Cc, D, Hh, W, kd, kh, kw, sd, sh, sw, pd, ph, pw, OD, OH, OW)
+        self.gp = C.byref(self.g)
+        self.in_shape, self.out_shape = tuple(x_shape), (N, Cc, OD, OH, OW)
+
+
+@functools.lru_cache(maxsize=None)
+def pool_plan(x_shape, k, s, p):
+    return PoolPlan(x_shape, k, s, p)
+
+
+def maxpool_fwd(plan, x, want_argmax=True):
+    y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    am = torch.empty(plan.out_shape, dtype=torch.int32, device=x.device) if want_argmax else None
+    H.call('gca_maxpool3d_fwd', plan.gp, ptr(x), ptr(y), ptr(am), stream())
+    return y, am
+
+
+def maxpool_bwd(plan, dy, argmax, dx=None, accumulate=False):
+    if dx is None:
+        dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        accumulate = False
+    H.call('gca_maxpool3d_bwd', plan.gp, ptr(dy), ptr(argmax), ptr(dx), int(accumulate), stream())
+    return dx
+
+
+def wavgpool_fwd(x, wt, norm):
+    N, Cc, D, Hh, W = x.shape
+    y = torch.empty((N, Cc), dtype=F32, device=x.device)
+    H.call('gca_wavgpool_fwd', ptr(x), ptr(wt), float(norm), N * Cc, D, Hh * W, ptr(y), stream())
+    return y
+
+
+def wavgpool_bwd(dy, wt, norm, x_shape):
+    N, Cc, D, Hh, W = x_shape
+    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
+    H.call('gca_wavgpool_bwd', ptr(dy), ptr(wt), float(norm), N * Cc, D, Hh * W, ptr(dx), stream())
+    return dx
+
+
+# ----------------------------------------------------------------------------- head pieces
+def relu_fwd(x):
+    y = torch.empty_like(x)
+    H.call('gca_relu_fwd', ptr(x), x.numel(), ptr(y), stream())
+    return y
+
+
+def relu_bwd(dy, y):
+    dx = torch.empty_like(dy)
+    H.call('gca_relu_bwd', ptr(dy), ptr(y), dy.numel(), ptr(dx), stream())
+    return dx
+
+
+def l2norm_fwd(x, eps=1e-12):
+    rows, dim = x.shape
+    y = torch.empty_like(x)
+    inv = torch.empty(rows, dtype=F32, device=x.device)
+    H.call('gca_l2norm_fwd', ptr(x), rows, dim, float(eps), ptr(y), ptr(inv), stream())
+    return y, inv
+
+
+def l2norm_bwd(dy, y, inv):
+    rows, dim = y.shape
+    dx = torch.empty_like(y)
+    H.call('gca_l2norm_bwd', ptr(dy), ptr(y), ptr(inv), rows, dim, ptr(dx), stream())
+    return dx
+
+
+def negcos(p, z, scale, loss_buf, accumulate):
+    """loss_buf: (1 + rows) floats; returns dp."""
+    rows, dim = p.shape
+    dp = torch.empty_like(p)
+    H.call('gca_negcos_fwd_bwd', ptr(p), ptr(z), rows, dim, float(scale), ptr(loss_buf), int(accumulate), ptr(dp),
+           stream())
+    return dp
+
+
+# ----------------------------------------------------------------------------- MoCo / InfoNCE
+def moco_logits_fwd(q, k, queue, inv_T, want_lse=False, want_rank=False):
+    b, D = q.shape
+    K = queue.shape[0]
+    logits = torch.empty((b, K + 1), dtype=F32, device=q.device)
+    lse = torch.empty(b, dtype=F32, device=q.device) if want_lse else None
+    rank = torch.empty(b, dtype=torch.int32, device=q.device) if want_rank else None
+    H.call('gca_moco_logits_fwd', ptr(q), ptr(k), ptr(queue), b, K, D, float(inv_T), ptr(logits), ptr(lse), ptr(rank),
+           None, stream())
+    return logits, lse, rank
+
+
+def nce_loss_fwd(logits, lse=None):
+    b, ncol = logits.shape
+    loss = torch.empty(1, dtype=F32, device=logits.device)
+    lse_out = None
+    if lse is None:
+        lse_out = torch.empty(b, dtype=F32, device=logits.device)
+    H.call('gca_nce_softmax_loss_fwd', ptr(logits), b, ncol, ptr(lse), ptr(lse_out), ptr(loss), stream())
+    return loss, (lse if lse is not None else lse_out)
+
+
+def nce_loss_bwd(logits, lse, gscale_dev=None, gscale_host=1.0):
+    b, ncol = logits.shape
+    dl = torch.empty_like(logits)
+    H.call('gca_nce_softmax_loss_bwd', ptr(logits), ptr(lse), b, ncol, ptr(gscale_dev), float(gscale_host), ptr(dl),
+           stream())
+    return dl
+
+
+def moco_logits_bwd(k, queue, inv_T, dlogits=None, logits=None, lse=None, gscale_dev=None, gscale_host=1.0,
+                    ov_start=0, ov_rows=None, ov_start_dev=None):
+    b, D = k.shape
+    K = queue.shape[0]
+    dq = torch.empty((b, D), dtype=F32, device=k.device)
+    ws = WS.get(H.lib.gca_infonce_ws_bytes(b, K), k.device)
+    ov_n = 0 if ov_rows is None else ov_rows.shape[0]
+    H.call('gca_moco_logits_bwd', ptr(dlogits), ptr(logits), ptr(lse), ptr(gscale_dev), float(gscale_host), ptr(k),
+           ptr(queue), b, K, D, float(inv_T), int(ov_start), ptr(ov_start_dev), int(ov_n), ptr(ov_rows), ptr(dq),
+           ptr(ws), stream())
+    return dq
+
+
+def queue_enqueue(queue, keys, ptr_index, save=False, ptr_dev=None):
+    K, D = queue.shape
+    n = keys.shape[0]
+    saved = torch.empty((n, D), dtype=F32, device=queue.device) if save else None
+    H.call('gca_queue_enqueue', ptr(queue), K, D, ptr(keys), n, int(ptr_index), ptr(ptr_dev), ptr(saved), stream())
+    return saved
+
+
+def queue_advance(ptr_dev, n, K):
+    H.call('gca_queue_advance', ptr(ptr_dev), int(n), int(K), stream())
+
+
+# ----------------------------------------------------------------------------- graph block
+def graph_adj_fwd(gq, gk, u, max_hop, alpha, temperature):
+    B, Ci, T = gq.shape[0], gq.shape[1], gq.shape[2]
+    HW = gq.shape[3] * gq.shape[4]
+    out = torch.empty((3, B, T, T), dtype=F32, device=gq.device)
+    H.call('gca_graph_adj_fwd', ptr(gq), ptr(gk), B, Ci, T, HW, int(max_hop), float(alpha), float(temperature), ptr(u),
+           ptr(out[0]), ptr(out[1]), ptr(out[2]), stream())
+    return out[0], out[1], out[2]          # sim, adj_pre, adj
+
+
+def graph_adj_bwd(dadj, gq, gk, sim, pre, adj, max_hop, alpha, temperature):
+    B, Ci, T = gq.shape[0], gq.shape[1], gq.shape[2]
+    HW = gq.shape[3] * gq.shape[4]
+    dgq, dgk = torch.empty_like(gq), torch.empty_like(gk)
+    H.call('gca_graph_adj_bwd', ptr(dadj), ptr(gq), ptr(gk), ptr(sim), ptr(pre), ptr(adj), B, Ci, T, HW, int(max_hop),
+           float(alpha), float(temperature), ptr(dgq), ptr(dgk), stream())
+    return dgq, dgk
+
+
+def graph_gcn_fwd(adj, s):
+    B, Cc, T = s.shape[0], s.shape[1], s.shape[2]
+    out = torch.empty_like(s)
+    H.call('gca_graph_gcn_fwd', ptr(adj), ptr(s), B, Cc, T, s.shape[3] * s.shape[4], ptr(out), stream())
+    return out
+
+
+def graph_gcn_bwd(adj, s, dout, want_dadj=True):
+    B, Cc, T = s.shape[0], s.shape[1], s.shape[2]
+    ds = torch.empty_like(s)
+    dadj = torch.empty((B, T, T), dtype=F32, device=s.device) if want_dadj else None
+    H.call('gca_graph_gcn_bwd', ptr(adj), ptr(s), ptr(dout), B, Cc, T, s.shape[3] * s.shape[4], ptr(ds), ptr(dadj),
+           None, stream())
+    return ds, dadj
+
+
+# ----------------------------------------------------------------------------- flat-arena updates
+def ema_update(p_ema, p, m):
+    H.call('gca_ema_update', ptr(p_ema), ptr(p), p.numel(), float(m), stream())
+
+
+def sgd_step(p, g, buf, chunk_lr, chunk_wd, lr_scale, momentum, nesterov):
+    H.call('gca_sgd_step', ptr(p), ptr(g), ptr(buf), p.numel(), ptr(chunk_lr), ptr(chunk_wd), float(lr_scale),
+           float(momentum), int(nesterov), 0, stream())
+
+
+def fill(t, v):
+    H.call('gca_fill', ptr(t), t.numel(), float(v), stream())
+
+
+def axpy(y, x, a=1.0):
+    H.call('gca_axpy', ptr(y), ptr(x), y.numel(), float(a), stream())
+
+
+def scale_(y, a):
+    H.call('gca_scale', ptr(y), y.numel(), float(a), stream())
+
+
+def gather_rows(src, idx):
+    rows = idx.numel()
+    re = src.numel() // src.shape[0]
+    dst = torch.empty((rows,) + tuple(src.shape[1:]), dtype=F32, device=src.device)
+    H.call('gca_gather_rows', ptr(src), ptr(idx), rows, re, ptr(dst), stream())
+    return dst

@@ -1,0 +1,47 @@
+"""Minimal reverse-mode tape for the HIP engine.
+
+The encoder is a static DAG of a few dozen coarse fused ops (conv+BN+ReLU(+residual), pools,
+linears), so instead of one autograd node per ATen call the engine records one closure per
+fused op and replays them in reverse.  torch.autograd only ever sees ONE node per model
+(engine/autograd_bridge.py), which keeps the reference's ``loss.backward()`` API working.
+"""
+import torch
+
+from . import ops
+
+
+class Var:
+    """A tensor travelling through the engine plus its (lazily created) gradient buffer."""
+    __slots__ = ('t', 'grad', 'needs_grad')
+
+    def __init__(self, t, needs_grad=False):
+        self.t = t
+        self.grad = None
+        self.needs_grad = needs_grad
+
+    def grad_buffer(self):
+        """-> (buffer, accumulate): kernels that can add in place write straight into it."""
+        if self.grad is None:
+            self.grad = torch.empty_like(self.t)
+            return self.grad, False
+        return self.grad, True
+
+    def add_grad(self, g):
+        if self.grad is None:
+            self.grad = g
+        else:
+            ops.axpy(self.grad, g, 1.0)
+
+
+class Tape:
+    def __init__(self, recording):
+        self.recording = recording
+        self.fns = []
+
+    def record(self, fn):
+        if self.recording:
+            self.fns.append(fn)
+
+    def backward(self):
+        while self.fns:
+            self.fns.pop()()

@@ -1,0 +1,219 @@
+"""Pre-training step drivers (MoCo and SimSiam) on the HIP engine.
+
+Restates the iteration of tools/train_video_contrast_dis.py:395-454 (_train_moco) and :479-523
+(_train_simsiam) without its host syncs (3x .item() per iteration, :429-431) and defects
+(SURVEY.md fact 7).  One iteration =
+
+    key encoder fwd (no grad, BN in train mode)      ShuffleBN exchange / negatives all-gather (N>1)
+    query encoder fwd                                InfoNCE: logits GEMM + LSE + loss + top-k rank
+    enqueue keys -> queue                            dq -> encoder backward (tape)
+    gradient all-reduce (N>1) -> fused SGD           fused EMA of the key encoder
+
+Everything between the collectives is a fixed kernel sequence, so it is captured into hipGraphs
+(one for N=1; three segments around the collectives for N>1) and replayed per step.
+"""
+import torch
+
+from . import ops
+from .arena import arena_of
+from .tape import Tape, Var
+from .. import parallel as par
+from ..lib.memory import create_contrast, create_criterion
+from ..lib.modeling import create_visual_model
+from ..lib.solver import make_lr_scheduler, make_optimizer
+
+
+def set_key_encoder_mode(model_ema):
+    """eval() but every BatchNorm stays in train mode (tools/...dis.py:383-389)."""
+    model_ema.eval()
+    for m in model_ema.modules():
+        if m.__class__.__name__.find('BatchNorm') != -1:
+            m.train()
+
+
+class _Graphed(object):
+    """Capture-once / replay wrapper for a no-argument closure working on static buffers."""
+
+    def __init__(self, fn, enabled):
+        self.fn, self.enabled, self.graph, self.warm = fn, enabled, None, 0
+
+    def run(self):
+        if not self.enabled:
+            return self.fn()
+        if self.graph is None:
+            if self.warm < 2:               # eager warm-up: builds plans/tables/workspaces, warms allocator
+                self.warm += 1
+                return self.fn()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):        # records the launches, does not execute them
+                self.fn()
+            self.graph = g
+        self.graph.replay()
+
+
+class MoCoTrainer(object):
+    def __init__(self, cfg, device, ctx=None, use_graph=True, seed=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.ctx = ctx or par.DistCtx()
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.model, self.model_ema = create_visual_model(cfg)
+        self.model.to(self.device)
+        self.model_ema.to(self.device)
+        self.arena_q, self.arena_k = arena_of(self.model), arena_of(self.model_ema)
+        if self.arena_q.total != self.arena_k.total:
+            raise RuntimeError('query / key encoders must share one parameter layout')
+        par.broadcast_(self.arena_q.flat, self.ctx)
+        self.arena_k.flat.copy_(self.arena_q.flat)                       # _momentum_update(m=0), :146
+        self.contrast = create_contrast(cfg, 0).to(self.device)
+        par.broadcast_(self.contrast.memory, self.ctx)                    # _broadcast_memory, :121
+        self.criterion = create_criterion(cfg, 0)
+        self.optimizer = make_optimizer(cfg, self.model)
+        self.scheduler = make_lr_scheduler(cfg, self.optimizer)
+        self.model.train()
+        set_key_encoder_mode(self.model_ema)
+        self.alpha = float(cfg.CONTRAST.ALPHA)
+        self.inv_T = 1.0 / float(cfg.CONTRAST.NCE_T)
+        self.K = int(cfg.CONTRAST.NCE_K)
+        self.ptr_dev = torch.zeros(1, dtype=torch.long, device=self.device)
+        self.use_graph = bool(use_graph)
+        self.step_count = 0
+        self.perm_seed = int(getattr(cfg.MODEL, 'SEED', 1))
+        self._static = None
+        self._segments = None
+        self.out = {}
+
+    # -------------------------------------------------------------------------------- buffers
+    def _ensure_static(self, images):
+        b = images.shape[0]
+        if self._static is None or self._static['images'].shape != images.shape:
+            W = self.ctx.world
+            D = int(self.cfg.CROSS.FEAT_DIM)
+            self._static = dict(
+                images=torch.empty_like(images),
+                key_in=torch.empty((b,) + (3,) + tuple(images.shape[2:]), dtype=images.dtype, device=self.device)
+                if self.ctx.active else None,
+                k_shuf=torch.empty((b, D), dtype=torch.float32, device=self.device),
+                k=torch.empty((b, D), dtype=torch.float32, device=self.device),
+                all_k=torch.empty((b * W, D), dtype=torch.float32, device=self.device),
+                enq_idx=torch.empty(b, dtype=torch.long, device=self.device))
+            self._segments = None
+        return self._static
+
+    # -------------------------------------------------------------------------------- phases
+    def _phase_key(self):
+        """k (shuffled order on N>1) = key_encoder(key_in); no tape, BN train mode."""
+        s = self._static
+        x2 = s['key_in'] if self.ctx.active else torch.chunk(s['images'], 2, dim=1)[1]
+        kv = self.model_ema.fwd(Tape(False), Var(x2))
+        s['k_shuf'].copy_(kv.t)
+
+    def _phase_query(self):
+        s = self._static
+        b = s['images'].shape[0]
+        self.optimizer.zero_grad()
+        tape = Tape(True)
+        qv = self.model.fwd(tape, Var(torch.chunk(s['images'], 2, dim=1)[0]))
+        mem = self.contrast.memory
+        logits, lse, rank = ops.moco_logits_fwd(qv.t, s['k'], mem, self.inv_T, want_lse=True, want_rank=True)
+        loss, _ = ops.nce_loss_fwd(logits, lse)
+        saved = ops.queue_enqueue(mem, s['all_k'], 0, save=True, ptr_dev=self.ptr_dev)
+        # DDP averages gradients: fold 1/world into the loss-gradient scale
+        qv.grad = ops.moco_logits_bwd(s['k'], mem, self.inv_T, logits=logits, lse=lse,
+                                      gscale_host=1.0 / self.ctx.world, ov_rows=saved, ov_start_dev=self.ptr_dev)
+        ops.queue_advance(self.ptr_dev, s['all_k'].shape[0], self.K)
+        tape.backward()
+        self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
+
+    def _phase_update(self):
+        self.optimizer.step()
+        ops.ema_update(self.arena_k.flat, self.arena_q.flat, self.alpha)      # :440
+
+    def _single_gpu_all(self):
+        s = self._static
+        self._phase_key()
+        # N=1: BN batch statistics are permutation invariant, so the clips are NOT physically shuffled;
+        # only the enqueue order (all_k = k in shuffled order, :222) is reproduced.
+        s['k'].copy_(s['k_shuf'])
+        s['all_k'].copy_(ops.gather_rows(s['k_shuf'], s['enq_idx']))
+        self._phase_query()
+        self._phase_update()
+
+    # -------------------------------------------------------------------------------- step
+    def train_step(self, images, shuffle_ids=None):
+        """images: (b, 6, T, H, W) fp32 on the device.  Returns dict(loss, logits, rank, q) of device
+        tensors (no host sync).  shuffle_ids: optional host int64 permutation of the node batch."""
+        if images.device != self.device or images.dtype != torch.float32:
+            raise RuntimeError('train_step needs fp32 clips already resident on %s' % self.device)
+        s = self._ensure_static(images)
+        b, W = images.shape[0], self.ctx.world
+        if shuffle_ids is None:
+            shuffle_ids = par.shared_permutation(b * W, self.perm_seed, self.step_count)
+        s['images'].copy_(images)
+        self.optimizer._sync_tables()
+        if not self.ctx.active:
+            s['enq_idx'].copy_(shuffle_ids)
+            if self._segments is None:
+                self._segments = [_Graphed(self._single_gpu_all, self.use_graph)]
+            self._segments[0].run()
+        else:
+            if self._segments is None:
+                self._segments = [_Graphed(self._phase_key, self.use_graph), _Graphed(self._phase_query, self.use_graph),
+                                  _Graphed(self._phase_update, self.use_graph)]
+            x2 = torch.chunk(s['images'], 2, dim=1)[1]
+            s['key_in'].copy_(par.shuffle_exchange(x2, shuffle_ids, self.ctx, ops.gather_rows))
+            self._segments[0].run()
+            s['all_k'].copy_(par.gather_keys(s['k_shuf'], self.ctx))
+            s['k'].copy_(par.unshuffle_keys(s['all_k'], shuffle_ids, b, self.ctx, ops.gather_rows))
+            self._segments[1].run()
+            par.allreduce_sum_(self.arena_q.grad, self.ctx)
+            self._segments[2].run()
+        self.contrast.index = (self.contrast.index + b * W) % self.K      # host mirror of ptr_dev
+        self.step_count += 1
+        return self.out
+
+    def state_dict(self, epoch=0):
+        """Checkpoint dict with the reference's keys (tools/...dis.py:274-286) + the queue pointer."""
+        return {'epoch': epoch, 'state_dict': self.model.state_dict(), 'optimizer': self.optimizer.state_dict(),
+                'contrast': self.contrast.state_dict(), 'model_ema': self.model_ema.state_dict(),
+                'queue_index': int(self.contrast.index)}
+
+
+class SimSiamTrainer(object):
+    def __init__(self, cfg, device, ctx=None, use_graph=True, seed=None):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.ctx = ctx or par.DistCtx()
+        if seed is not None:
+            torch.manual_seed(seed)
+        self.model, ema = create_visual_model(cfg)
+        if ema is not None:
+            raise ValueError('SimSiamTrainer needs CONTRAST.MEM_TYPE == simsiam')
+        self.model.to(self.device)
+        self.arena = arena_of(self.model)
+        par.broadcast_(self.arena.flat, self.ctx)
+        self.optimizer = make_optimizer(cfg, self.model)
+        self.scheduler = make_lr_scheduler(cfg, self.optimizer)
+        self.model.train()
+        self.use_graph = bool(use_graph)
+        self._static, self._segments, self.out = None, None, {}
+
+    def _fwd_bwd(self):
+        self.optimizer.zero_grad()
+        tape = Tape(True)
+        lv = self.model.fwd(tape, Var(self._static))
+        tape.backward()
+        self.out = dict(loss=lv.t)
+
+    def train_step(self, images):
+        if self._static is None or self._static.shape != images.shape:
+            self._static = torch.empty_like(images)
+            self._segments = [_Graphed(self._fwd_bwd, self.use_graph), _Graphed(self.optimizer.step, self.use_graph)]
+        self._static.copy_(images)
+        self.optimizer._sync_tables()
+        self._segments[0].run()
+        if self.ctx.active:
+            par.allreduce_sum_(self.arena.grad, self.ctx)
+            ops.scale_(self.arena.grad, 1.0 / self.ctx.world)
+        self._segments[1].run()
+        return self.out

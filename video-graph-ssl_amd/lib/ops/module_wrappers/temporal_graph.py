@@ -1,0 +1,117 @@
+"""Temporal-graph augmentation block on the HIP engine.
+
+Reference: lib/ops/module_wrappers/temporal_graph.py.  The reference block cannot even be
+constructed (ctor calls the non-existent ``reset_parameter``, :117/:124) and is never inserted
+(SURVEY.md fact 5); what is implemented here is the arithmetic of its ``forward`` (:227-239) with the
+defaults of :67-70: hop-distance graph over the T frames (:7-36), similarity adjacency from two
+1x1x1 convs + (1,2,2) max-pool + T x T matmul + softmax (:150-178), hop weighting theta(h) (:204-210),
+RelaxedBernoulli re-sampling (:187-192) and ONE GCN layer C->C: 1x1x1 conv, dense neighbourhood
+aggregation einsum('bij,bcjhw->bcihw') and skip (:56-64).  Parameter names match the reference
+(gcns.0.conv.weight, g_q.0.weight, g_k.0.weight).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ....engine import layers as L, ops
+from ....engine.layers import HipConv3d, HipMaxPool3d
+from ....engine.tape import Var
+
+
+class TemporalGraph(object):
+    """Hop distances of the chain graph over `tem_len` frames: |i-j| if <= max_hop else inf (:7-36)."""
+
+    def __init__(self, tem_len=16, max_hop=1, dilation=1):
+        self.max_hop, self.dilation, self.num_node = max_hop, dilation, tem_len
+        idx = torch.arange(tem_len)
+        d = (idx[:, None] - idx[None, :]).abs().float()
+        self.temporal_graph = torch.where(d <= max_hop, d, torch.full_like(d, float('inf')))
+
+
+class GCN(nn.Module):
+    def __init__(self, in_features, out_features=None, bias=False, skip=True):
+        super().__init__()
+        if not skip:
+            raise NotImplementedError('the reference always uses skip=True')
+        self.skip = skip
+        self.in_features = in_features
+        self.out_features = in_features if out_features is None else out_features
+        self.conv = HipConv3d(in_features, self.out_features, (1, 1, 1), bias=bias)
+
+    def fwd(self, tape, xv, adjv):
+        sv = L.f_conv(tape, self.conv, xv)
+        s, adj = sv.t, adjv.t
+        out = ops.graph_gcn_fwd(adj, s)
+        ov = Var(out, tape.recording)
+
+        def back():
+            ds, dadj = ops.graph_gcn_bwd(adj, s, ov.grad, want_dadj=adjv.needs_grad)
+            ov.grad = None
+            sv.add_grad(ds)
+            if adjv.needs_grad:
+                adjv.add_grad(dadj)
+        tape.record(back)
+        return ov
+
+
+class TemporalGraphAug(nn.Module):
+    def __init__(self, in_channels, inter_channels=None, sub_sample=True, bias=False, bn_layer=False,
+                 zero_init=False, max_pool=True, mask_frame=False, nei_size=None, alpah=0.5, num_gcn_layers=1,
+                 temperature=1., max_hop=3):
+        super().__init__()
+        if bn_layer or mask_frame or not sub_sample or not max_pool or num_gcn_layers != 1:
+            raise NotImplementedError('only the reference defaults (temporal_graph.py:67-70) are on the hot path')
+        self.in_channels = in_channels
+        self.inter_channels = max(in_channels // 2, 1) if inter_channels is None else inter_channels
+        self.alpha, self.temperature, self.max_hop, self.bias = alpah, temperature, max_hop, bias
+        self.gcns = nn.ModuleList([GCN(in_features=in_channels, out_features=None)])   # C -> C (:95 passes None)
+        pool = HipMaxPool3d(kernel_size=(1, 2, 2))
+        q = HipConv3d(in_channels, self.inter_channels, 1, 1, 0, bias=bias)
+        k = HipConv3d(in_channels, self.inter_channels, 1, 1, 0, bias=bias)
+        self.reset_parameters(q, k, zero_init)
+        self.g_q = nn.Sequential(q, pool)
+        self.g_k = nn.Sequential(k, pool)
+        self.noise = None          # optional injected uniforms (B,T,T) for deterministic parity tests
+
+    def reset_parameters(self, m1, m2, zero_init=False):
+        """Uniform(-1/sqrt(fan_in), 1/sqrt(fan_in)) for the two similarity convs (:131-148)."""
+        for m in (m1, m2):
+            if zero_init:
+                nn.init.constant_(m.weight, 0)
+            else:
+                n = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2] * m.in_channels
+                m.weight.data.uniform_(-1. / math.sqrt(n), 1. / math.sqrt(n))
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0) if zero_init else m.bias.data.uniform_(-1. / math.sqrt(n), 1. / math.sqrt(n))
+
+    def fwd(self, tape, xv):
+        x = xv.t
+        B, T = x.shape[0], x.shape[2]
+        gq = L.f_maxpool(tape, self.g_q[1], L.f_conv(tape, self.g_q[0], xv))
+        gk = L.f_maxpool(tape, self.g_k[1], L.f_conv(tape, self.g_k[0], xv))
+        u = self.noise
+        if u is None:
+            u = torch.rand((B, T, T), device=x.device)        # RelaxedBernoulli.rsample's uniforms
+        sim, pre, adj = ops.graph_adj_fwd(gq.t, gk.t, u, self.max_hop, self.alpha, self.temperature)
+        adjv = Var(adj, tape.recording)
+
+        def back():
+            if adjv.grad is not None:
+                dgq, dgk = ops.graph_adj_bwd(adjv.grad, gq.t, gk.t, sim, pre, adj, self.max_hop, self.alpha,
+                                             self.temperature)
+                adjv.grad = None
+                gq.add_grad(dgq)
+                gk.add_grad(dgk)
+        tape.record(back)
+        out = xv
+        for g in self.gcns:
+            out = g.fwd(tape, out, adjv)
+        return out
+
+
+class AugThen(nn.Sequential):
+    """Sequential(TemporalGraphAug, module): what build_aug_block installs in place of `module`."""
+
+    def fwd(self, tape, xv):
+        return L.f_seq(tape, self[1], self[0].fwd(tape, xv))

@@ -1,0 +1,81 @@
+"""Optimiser / LR-schedule factories (reference: lib/solver/build.py:24-71).
+
+``make_optimizer(cfg, model)`` returns a HipSGD whose ``param_groups`` mirror the reference's
+(one group PER PARAMETER; names containing "bias" get lr * BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS),
+but whose ``step()`` is ONE multi-tensor kernel over the flat parameter arena instead of one
+launch per tensor."""
+import torch
+
+from .lr_scheduler import WarmupMultiStepLR
+from ...engine import ops
+from ...engine.arena import CHUNK, arena_of
+
+
+class HipSGD(object):
+    """torch.optim.SGD semantics (momentum, weight decay, optional nesterov; dampening 0) on the arena."""
+
+    def __init__(self, model, groups, momentum=0.9, nesterov=False):
+        self.arena = arena_of(model)
+        if len(groups) != len(self.arena.params):
+            raise ValueError('one param group per parameter expected')
+        self.param_groups = groups
+        for g in groups:
+            g.setdefault('initial_lr', g['lr'])
+            g.setdefault('momentum', momentum)
+            g.setdefault('nesterov', nesterov)
+        self.momentum, self.nesterov = momentum, nesterov
+        dev = self.arena.flat.device
+        self.buf = torch.zeros_like(self.arena.flat)          # momentum buffers (zero == "first step" semantics)
+        self.chunk_lr = torch.zeros(self.arena.total // CHUNK, dtype=torch.float32, device=dev)
+        self.chunk_wd = torch.zeros_like(self.chunk_lr)
+        self._uploaded = None
+        self._sync_tables()
+
+    def _sync_tables(self):
+        key = tuple((g['lr'], g['weight_decay']) for g in self.param_groups)
+        if key != self._uploaded:
+            self.chunk_lr.copy_(self.arena.chunk_table([g['lr'] for g in self.param_groups]), non_blocking=False)
+            self.chunk_wd.copy_(self.arena.chunk_table([g['weight_decay'] for g in self.param_groups]))
+            self._uploaded = key
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.rebind()
+        ops.fill(self.arena.grad, 0.0)
+
+    def step(self):
+        self._sync_tables()
+        ops.sgd_step(self.arena.flat, self.arena.grad, self.buf, self.chunk_lr, self.chunk_wd, 1.0,
+                     self.momentum, self.nesterov)
+
+    def state_dict(self):
+        return {'momentum_buffer': self.buf, 'param_groups': [{k: v for k, v in g.items() if k != 'params'}
+                                                              for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.buf.copy_(sd['momentum_buffer'])
+        for g, s in zip(self.param_groups, sd['param_groups']):
+            g.update(s)
+        self._uploaded = None
+
+
+def make_optimizer(cfg, model):
+    if cfg.SOLVER.USE_TRICK:
+        raise NotImplementedError('SOLVER.USE_TRICK (TSN-style policies) is a downstream-only path')
+    if cfg.SOLVER.OPTIMIZER_NAME != 'SGD':
+        raise NotImplementedError('only SGD is used by the pre-training configs')
+    groups = []
+    for key, value in model.named_parameters():
+        if not value.requires_grad:
+            raise NotImplementedError('frozen parameters are not on the pre-training path')
+        lr, wd = cfg.SOLVER.BASE_LR, cfg.SOLVER.WEIGHT_DECAY
+        if 'bias' in key:
+            lr, wd = cfg.SOLVER.BASE_LR * cfg.SOLVER.BIAS_LR_FACTOR, cfg.SOLVER.WEIGHT_DECAY_BIAS
+        groups.append({'params': [value], 'lr': lr, 'weight_decay': wd, 'name': key})
+    return HipSGD(model, groups, momentum=cfg.SOLVER.MOMENTUM, nesterov=cfg.SOLVER.NESTEROV)
+
+
+def make_lr_scheduler(cfg, optimizer):
+    return WarmupMultiStepLR(optimizer=optimizer, milestones=cfg.SOLVER.STEPS, gamma=cfg.SOLVER.GAMMA,
+                             warmup_factor=cfg.SOLVER.WARMUP_FACTOR, warmup_iters=cfg.SOLVER.WARMUP_ITERS,
+                             warmup_method=cfg.SOLVER.WARMUP_METHOD, mode=cfg.SOLVER.LR_SCHEDULER,
+                             max_epochs=cfg.SOLVER.MAX_EPOCHS)
