@@ -1,0 +1,322 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MoCo pre-training clips/sec (R(2+1)D-18, 16 x 112 x 112, 32 clips per GPU) on
+N MI355X of one node + InfoNCE forward ms, with the dominant kernel's roofline fraction and the CPU
+oracle timed beside it.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full pre-training iteration on one synthetic batch already resident in HBM: key
+encoder forward, query encoder forward + backward, InfoNCE logits / loss / top-k rank, enqueue,
+(gradient all-reduce, ShuffleBN exchange and negatives all-gather for N > 1), SGD step and EMA
+update -- nothing skipped.  One JSON line is printed by rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec)
+PEAK_HBM_GBPS = 8000.0            # HBM3E spec
+FWD_GFLOP_PER_VIEW = 16.953       # R(2+1)D-18 @16x112x112, conv+linear, 2*MAC
+
+
+def log(msg):
+    sys.stderr.write('[bench %7.1fs] %s\n' % (time.time() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.time()
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
+    ap.add_argument('--frames', type=int, default=16)
+    ap.add_argument('--size', type=int, default=112)
+    ap.add_argument('--backbone', default='R2P1D18')
+    ap.add_argument('--queue', type=int, default=0, help='0 = 4096 at N=1, 65536 at N>1 (BASELINE configs 2/3)')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def make_cfg(pkg, args, K):
+    cfg = pkg.get_defaults()
+    cfg.merge_from_list(['MODEL.BACKBONE', args.backbone, 'MODEL.BACKBONE_TYPE', '3D', 'MODEL.DROPOUT', 0.0,
+                         'MODEL.PRETRAINED', False, 'INPUT.VIDEO_LENGTH', args.frames, 'CONTRAST.MEM_TYPE', 'moco',
+                         'CONTRAST.NCE_K', K, 'CONTRAST.NCE_T', 0.07, 'CONTRAST.ALPHA', 0.999, 'CROSS.FEAT_DIM', 128,
+                         'SOLVER.BASE_LR', 0.06, 'SOLVER.LR_SCHEDULER', 'step', 'SOLVER.STEPS', [80, 120, 160],
+                         'SOLVER.WARMUP_FACTOR', 0.01, 'SOLVER.WARMUP_ITERS', 10, 'SOLVER.MAX_EPOCHS', 200])
+    return cfg
+
+
+def ev_time_ms(fn, reps, warm=3):
+    """Average ms of fn() measured with HIP events on the stream the kernels are launched on."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def conv_layers_of(model, x_shape, pkg):
+    """[(conv module, input shape)] in execution order, via a shape-only walk of the engine forward."""
+    rec = []
+    L = pkg.engine.layers
+    orig = L.HipConv3d.plan
+
+    def spy(self, x):
+        rec.append((self, tuple(x.shape), x.stride(0) if not x.is_contiguous() else 0))
+        return orig(self, x)
+    L.HipConv3d.plan = spy
+    try:
+        tp = importlib.import_module('video-graph-ssl_amd.engine.tape')
+        model.fwd(tp.Tape(False), tp.Var(torch.randn(x_shape, device='cuda')))
+    finally:
+        L.HipConv3d.plan = orig
+    seen, out = set(), []
+    for m, shp, xs in rec:           # plan() is called once per forward per conv (dedupe the pack call)
+        if id(m) not in seen:
+            seen.add(id(m))
+            out.append((m, shp, xs))
+    return out
+
+
+def _bm(dk):
+    """Mirror of use_bm64() in csrc/conv3d.hip: block-tile height the launcher picks for `dk` GEMM rows."""
+    if dk <= 64:
+        return 64
+    t128, t64 = -(-dk // 128) * 128, -(-dk // 64) * 64
+    return 64 if ((t128 - dk) * 4 > t128 and t64 < t128) else 128
+
+
+def kernel_timing(pkg, trainer, args):
+    """Time every conv launch of one training step (each conv layer's forward x2 [key+query], dgrad, wgrad)
+    with HIP events on the launch stream and aggregate per KERNEL SYMBOL (what rocprofv3 --stats reports):
+    achieved = algorithmic FLOPs of that symbol's launches in one step / their summed duration."""
+    ops = pkg.engine.ops
+    b = args.batch
+    enc = trainer.model.model.encoder.base_model
+    layers = conv_layers_of(enc, (b, 3, args.frames, args.size, args.size), pkg)
+    sym = {}
+
+    def add(name, ms, flops, times):
+        e = sym.setdefault(name, [0.0, 0.0, 0])
+        e[0] += ms * times; e[1] += flops * times; e[2] += times
+
+    dev = torch.device('cuda', torch.cuda.current_device())
+    for i, (m, shp, xs) in enumerate(layers):
+        plan = ops.conv_plan(shp, m.out_channels, m.kernel_size, m.stride, m.padding, dev)
+        N, K, OD, OH, OW = plan.out_shape
+        taps = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2]
+        flops = 2.0 * N * K * OD * OH * OW * shp[1] * taps
+        x = torch.randn(shp, device='cuda')
+        dy = torch.randn(plan.out_shape, device='cuda')
+        w = m.weight.data
+        wp0, wp1 = ops.conv_pack(plan, 0, w), ops.conv_pack(plan, 1, w)
+        dw = torch.zeros_like(w)
+        dx = torch.empty(shp, device='cuda')
+        t = ev_time_ms(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5, 1)
+        add('conv_igemm_kernel<%d,128,2,2,0>' % _bm(K), t, flops, 2)            # key + query forward
+        if i > 0:                                                              # the stem never needs d(input)
+            unit = tuple(m.stride) == (1, 1, 1)
+            t = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
+            add('conv_igemm_kernel<%d,128,2,2,%d>' % (_bm(shp[1]), 0 if unit else 1), t, flops, 1)
+        t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
+        add('conv_wgrad_kernel<%d,%d>' % (_bm(K), _bm(shp[1] * taps)), t, flops, 1)
+        del x, dy, dx
+    table = {k: dict(ms_per_step=round(v[0], 4), gflop_per_step=round(v[1] / 1e9, 2), launches_per_step=v[2],
+                     tflops=round((v[1] / 1e12) / (v[0] / 1e3), 3)) for k, v in sym.items()}
+    dom = max(sym, key=lambda k: sym[k][0])
+    ach = table[dom]['tflops']
+    roof = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4), launches_per_step=sym[dom][2],
+                flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1))
+    return roof, table
+
+
+def infonce_timing(pkg, b=32):
+    ops = pkg.engine.ops
+    out = {}
+    for K in (4096, 65536):
+        q = torch.nn.functional.normalize(torch.randn(b, 128, device='cuda'))
+        k = torch.nn.functional.normalize(torch.randn(b, 128, device='cuda'))
+        mem = torch.nn.functional.normalize(torch.randn(K, 128, device='cuda'))
+
+        def f():
+            logits, lse, rank = ops.moco_logits_fwd(q, k, mem, 1 / 0.07, want_lse=True, want_rank=True)
+            ops.nce_loss_fwd(logits, lse)
+        g = torch.cuda.CUDAGraph()
+        f()
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            f()
+        ms = ev_time_ms(g.replay, 200, 10)
+        bytes_alg = K * 128 * 4 + 2 * b * 128 * 4 + b * (K + 1) * 4
+        out['K%d' % K] = dict(ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2),
+                              GBps=round(bytes_alg / 1e9 / (ms / 1e3), 1),
+                              hbm_frac=round(bytes_alg / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4))
+    return out
+
+
+def host_cores():
+    """Usable host cores: min(affinity mask, cgroup CPU quota, cpu_count)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                if txt[0] != 'max':
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def cpu_baseline(args, K):
+    """The CPU oracle (oracle/: torch-CPU restatement pinned to the reference by golden fixtures) running the
+    same iteration on the host cores, on a bounded sample (b=4 clips), scaled per clip."""
+    from oracle import moco as omoco, wrappers as owrap
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    log('cpu baseline on %d host threads' % cores)
+    b = 4
+    torch.manual_seed(1)
+    model, ema = owrap.create_visual_model(args.backbone, args.frames, 128, 'mlp', 'moco')
+    ema.load_state_dict(model.state_dict())
+    contrast = omoco.RGBMoCo(128, K=K, T=0.07)
+    opt = omoco.make_optimizer(model, 0.06, 0.9, 5e-4)
+    model.train()
+    omoco.set_key_encoder_mode(ema)
+    crit = omoco.NCESoftmaxLoss()
+    images = torch.randn(b, 6, args.frames, args.size, args.size)
+    t0 = time.time()
+    omoco.moco_train_step(model, ema, contrast, crit, opt, images, 0.999)      # warm-up
+    log('cpu baseline warm-up iteration %.1fs' % (time.time() - t0))
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 10 and n < 20):
+        omoco.moco_train_step(model, ema, contrast, crit, opt, images, 0.999)
+        n += 1
+        if time.time() - t0 > 60:
+            break
+    dt = (time.time() - t0) / n
+    return dict(value=round(b / dt, 3), unit='clips/s', cores=cores, kind='port',
+                sample='%d full MoCo iterations of b=%d clips (%s, %dx%dx%d, K=%d) with the torch-CPU oracle, '
+                       '%d threads' % (n, b, args.backbone, args.frames, args.size, args.size, K, cores))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
+                             '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    pkg = importlib.import_module('video-graph-ssl_amd')
+    ctx = pkg.parallel.DistCtx()
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)      # "nccl" == RCCL on ROCm
+        ctx = pkg.parallel.DistCtx(rank, world, None)
+    K = args.queue or (4096 if world == 1 else 65536)
+    cfg = make_cfg(pkg, args, K)
+    tr = pkg.MoCoTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
+    if rank == 0:
+        log('trainer built')
+    torch.manual_seed(1 + rank)
+    images = torch.randn(args.batch, 6, args.frames, args.size, args.size, device=dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(args.warmup, 0) + 3):        # +3: two eager warm-up steps and the hipGraph capture
+        tr.train_step(images)
+        if rank == 0 and i < 4:
+            torch.cuda.synchronize()
+            log('warm-up step %d done' % i)
+    barrier()
+    if rank == 0:
+        log('timing %d steps' % args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.train_step(images)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(out['loss'].item())
+    if rank != 0:
+        return
+    log('timed region %.3fs, loss %.4f' % (dt, loss))
+    global_batch = args.batch * world
+    value = global_batch * args.steps / dt
+    step_gflop = 4 * FWD_GFLOP_PER_VIEW * args.batch if (args.backbone, args.frames, args.size) == ('R2P1D18', 16, 112) else None
+    res = {
+        'metric': 'pretrain_clips_per_sec', 'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'MoCo pre-training iteration, %s, %d-frame %dx%d clips, %d clips/GPU (global %d), '
+                               'queue K=%d, T=0.07, SGD+EMA (BASELINE.json configs[%d])'
+                               % (args.backbone, args.frames, args.size, args.size, args.batch, global_batch, K,
+                                  1 if world == 1 else 2),
+                   'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph},
+        'views_per_sec': round(2 * value, 3), 'final_loss': round(loss, 5),
+    }
+    if step_gflop:
+        res['step_tflops_algorithmic'] = round(step_gflop / 1e3 / (dt / args.steps), 3)
+    if world == 1:
+        res['infonce_fwd'] = infonce_timing(pkg, 32)
+        log('infonce timing done')
+        res['infonce_fwd_ms'] = res['infonce_fwd']['K4096']['ms']
+        if not args.no_kernel_timing:
+            res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
+            log('kernel timing done')
+        if not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args, K)
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()

@@ -42,6 +42,11 @@ class Golden:
     def keys(self):
         return list(self.z.files)
 
+    def x(self, key):
+        """Regenerate a seeded input from its stored (seed, *shape) spec (see make_golden.seeded_randn)."""
+        sp = [int(v) for v in self.z[key]]
+        return torch.randn(*sp[1:], generator=torch.Generator().manual_seed(sp[0]))
+
 
 @pytest.fixture(scope='session')
 def golden():

@@ -63,6 +63,15 @@ def npz(name, **arrs):
     print('%-28s %8.1f KB' % (name + '.npz', os.path.getsize(path) / 1024))
 
 
+def seeded_randn(seed, *shape):
+    """Big inputs are not stored: tests regenerate them from (seed, shape) with the same CPU generator."""
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(int(seed)))
+
+
+def spec(seed, *shape):
+    return np.array([seed] + list(shape), dtype=np.int64)
+
+
 def sd_np(mod, prefix='w:'):
     return {prefix + k: v.clone() for k, v in mod.state_dict().items()}
 
@@ -76,7 +85,7 @@ def cfg_for(backbone, mem_type, feat_dim=128, T=8):
                         OPTIMIZER_NAME='SGD', STEPS=[80, 120, 160], GAMMA=0.1, WARMUP_FACTOR=0.01,
                         WARMUP_ITERS=10, WARMUP_METHOD='linear', LR_SCHEDULER='step', MAX_EPOCHS=200),
               CROSS=NS(FEAT_DIM=feat_dim, HEAD_TYPE='mlp', MODALITY='visual', CRITERION='crossentropy'),
-              CONTRAST=NS(MEM_TYPE=mem_type, NCE_K=16, NCE_T=0.07, NCE_M=0.5, ALPHA=0.999))
+              CONTRAST=NS(MEM_TYPE=mem_type, NCE_K=20, NCE_T=0.07, NCE_M=0.5, ALPHA=0.999))
 
 
 # ------------------------------------------------------------------ 1. per-op vectors
@@ -191,11 +200,11 @@ def gen_models():
     torch.manual_seed(21)
     m = resnet2p1d.generate_model(10, widen_factor=0.125)
     out.update(sd_np(m, 'r2t:w:'))
-    x = torch.randn(2, 3, 8, 32, 32, requires_grad=True)
+    x = seeded_randn(210, 4, 3, 8, 64, 64).requires_grad_(True)
     m.train()
     y = m(x)
     y.square().sum().backward()
-    out.update({'r2t:x': x, 'r2t:y_train': y, 'r2t:dx': x.grad,
+    out.update({'r2t:xspec': spec(210, 4, 3, 8, 64, 64), 'r2t:y_train': y, 'r2t:dx': x.grad,
                 'r2t:dw_conv1_s': m.conv1_s.weight.grad, 'r2t:dw_l4_conv2_t': m.layer4[0].conv2_t.weight.grad,
                 'r2t:dw_fc': m.fc.weight.grad, 'r2t:dg_bn1_s': m.bn1_s.weight.grad})
     out.update(sd_np(m, 'r2t:after:'))
@@ -219,29 +228,26 @@ def gen_models():
     full = {}
     s3d = check_same(s3d_1.S3D, oenc.S3D, 31)
     s3d.train()
-    torch.manual_seed(32)
-    xs = torch.randn(2, 3, 16, 32, 32)
+    xs = seeded_randn(32, 2, 3, 16, 96, 96)
     s3d.fc = nn.Identity()
     with torch.no_grad():
         ys = s3d(xs)
-    full.update({'s3d:seed': 31, 's3d:x': xs, 's3d:y_train': ys,
+    full.update({'s3d:seed': 31, 's3d:xspec': spec(32, 2, 3, 16, 96, 96), 's3d:y_train': ys,
                  's3d:rm_base0_bn_s': s3d.base[0].bn_s.running_mean})
     r18 = check_same(lambda: resnet2p1d.generate_model(18), lambda: oenc.R2Plus1D(18), 33)
     r18.train()
-    torch.manual_seed(34)
-    xr = torch.randn(2, 3, 8, 32, 32)
+    xr = seeded_randn(34, 4, 3, 8, 96, 96)
     r18.fc = nn.Identity()
     with torch.no_grad():
         yr = r18(xr)
-    full.update({'r18:seed': 33, 'r18:x': xr, 'r18:y_train': yr})
-    r3 = check_same(lambda: resnet.resnet18(sample_size=32, sample_duration=16),
-                    lambda: oenc.R3D(18, 32, 16), 35)
+    full.update({'r18:seed': 33, 'r18:xspec': spec(34, 4, 3, 8, 96, 96), 'r18:y_train': yr})
+    r3 = check_same(lambda: resnet.resnet18(sample_size=96, sample_duration=16),
+                    lambda: oenc.R3D(18, 96, 16), 35)
     r3.train()
-    torch.manual_seed(36)
-    x3 = torch.randn(2, 3, 16, 32, 32)
+    x3 = seeded_randn(36, 4, 3, 16, 96, 96)
     with torch.no_grad():
         y3 = r3(x3)
-    full.update({'r3d18:seed': 35, 'r3d18:x': x3, 'r3d18:y_train': y3})
+    full.update({'r3d18:seed': 35, 'r3d18:xspec': spec(36, 4, 3, 16, 96, 96), 'r3d18:y_train': y3})
     check_same(lambda: resnet.resnet50(sample_size=224, sample_duration=32), lambda: oenc.R3D(50, 224, 32), 37)
     npz('encoders_seeded', **full)
 
@@ -329,11 +335,11 @@ def gen_steps():
     assert ema is None
     model.train()
     out.update(sd_np(model, 'ss:w:'))
-    imgs = torch.randn(4, 6, 8, 32, 32)
+    imgs = seeded_randn(610, 8, 6, 8, 48, 48)
     loss = model(imgs)
     loss.backward()
     sm = model.model
-    out.update({'ss:x': imgs, 'ss:loss': loss, 'ss:dw_pred_l2': sm.prediction.l2.weight.grad,
+    out.update({'ss:xspec': spec(610, 8, 6, 8, 48, 48), 'ss:loss': loss, 'ss:dw_pred_l2': sm.prediction.l2.weight.grad,
                 'ss:dw_proj_l1': sm.projection.l1[0].weight.grad,
                 'ss:dg_proj_l3_bn': sm.projection.l3[1].weight.grad,
                 'ss:dw_conv1_s': sm.encoder.base_model.conv1_s.weight.grad})
@@ -346,7 +352,7 @@ def gen_steps():
     model, ema = ref_build.create_visual_model(cfg)
     for p1, p2 in zip(model.parameters(), ema.parameters()):          # _momentum_update(m=0), :146
         p2.data.mul_(0).add_(p1.detach().data, alpha=1)
-    contrast = mem_moco.RGBMoCo(32, K=16, T=0.07)
+    contrast = mem_moco.RGBMoCo(32, K=20, T=0.07)
     crit = ref_crit.NCESoftmaxLoss()
     opt = ref_solver.make_optimizer(cfg, model)
     sched = ref_solver.make_lr_scheduler(cfg, opt)
@@ -361,9 +367,9 @@ def gen_steps():
     for m in ema.modules():
         if 'BatchNorm' in m.__class__.__name__:
             m.train()
-    for it in range(2):
-        images = torch.randn(4, 6, 8, 32, 32)
-        shuffle_ids = torch.randperm(4)
+    for it in range(3):
+        images = seeded_randn(620 + it, 8, 6, 8, 48, 48)
+        shuffle_ids = torch.randperm(8)
         x1, x2 = torch.chunk(images, 2, dim=1)
         reverse_ids = torch.argsort(shuffle_ids)
         with torch.no_grad():
@@ -378,7 +384,7 @@ def gen_steps():
         opt.step()
         for p1, p2 in zip(model.parameters(), ema.parameters()):
             p2.data.mul_(0.999).add_(p1.detach().data, alpha=1 - 0.999)
-        out.update({'mo:images%d' % it: images, 'mo:shuffle%d' % it: shuffle_ids, 'mo:loss%d' % it: loss,
+        out.update({'mo:xspec%d' % it: spec(620 + it, 8, 6, 8, 48, 48), 'mo:shuffle%d' % it: shuffle_ids, 'mo:loss%d' % it: loss,
                     'mo:logits%d' % it: logits, 'mo:q%d' % it: feat_q, 'mo:k%d' % it: feat_k})
     out.update(sd_np(model, 'mo:after:'))
     ek = ema.state_dict()
@@ -387,8 +393,8 @@ def gen_steps():
                 'model.encoder.base_model.layer2.0.downsample.1.running_var',
                 'model.proj_head.head.0.bias', 'model.proj_head.head.2.weight'):
         out['mo:afterk:' + key] = ek[key].clone()
-    out['mo:mem2'] = contrast.memory.clone()
-    out['mo:ptr2'] = contrast.index
+    out['mo:mem3'] = contrast.memory.clone()
+    out['mo:ptr3'] = contrast.index
     # LR schedule (reference class, runnable thanks to shim 5)
     lrs = []
     for e in range(0, 200):

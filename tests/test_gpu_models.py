@@ -80,7 +80,7 @@ def test_r2plus1d_tiny_fwd_bwd_golden(pkg, golden):
     m = r2.generate_model(10, widen_factor=0.125)
     m.load_state_dict(g.group('r2t:w:'))
     m.to(DEV).train()
-    x = g.t('r2t:x').to(DEV)
+    x = g.x('r2t:xspec').to(DEV)
     yref = g.t('r2t:y_train')
     y, dx = _run(pkg, m, x, dy=(2 * yref).to(DEV))          # d/dy of sum(y^2), evaluated at the reference y
     assert rel_err(y, yref) < 1e-3
@@ -102,11 +102,11 @@ def test_full_size_encoders_seeded_golden(pkg, golden, tag, name, strip):
     g = golden('encoders_seeded')
     bb = pkg.lib.modeling.backbone.backbone_3d
     torch.manual_seed(int(g.t(tag + ':seed')))
-    m = getattr(bb, name)() if name else bb.resnet.resnet18(sample_size=32, sample_duration=16)
+    m = getattr(bb, name)() if name else bb.resnet.resnet18(sample_size=96, sample_duration=16)
     if strip:
         m.fc = pkg.engine.layers.HipIdentity()
     m.to(DEV).train()
-    y, _ = _run(pkg, m, g.t(tag + ':x').to(DEV))
+    y, _ = _run(pkg, m, g.x(tag + ':xspec').to(DEV))
     assert rel_err(y, g.t(tag + ':y_train')) < 1e-3
     if tag == 's3d':
         assert rel_err(m.base[0].bn_s.running_mean, g.t('s3d:rm_base0_bn_s')) < 1e-3
@@ -131,8 +131,8 @@ def test_project_head_and_api_autograd(pkg, golden):
     contrast = pkg.create_contrast(cfg, 0).to(DEV)
     mem0 = contrast.memory.detach().cpu().clone()
     crit = pkg.create_criterion(cfg, 0)
-    x = torch.randn(3, 3, 8, 32, 32)
-    k = torch.nn.functional.normalize(torch.randn(3, 32))
+    x = torch.randn(6, 3, 8, 64, 64)
+    k = torch.nn.functional.normalize(torch.randn(6, 32))
     feat_q = model(x.to(DEV))                       # GraphWrapper.forward, differentiable as ONE autograd node
     logits, labels = contrast(feat_q, k.to(DEV))
     loss = crit(logits)
@@ -146,7 +146,7 @@ def test_project_head_and_api_autograd(pkg, golden):
     oloss = omoco.NCESoftmaxLoss()(ol)
     oloss.backward()
     assert rel_err(logits, ol) < 1e-3 and rel_err(loss, oloss) < 1e-3
-    assert torch.equal(labels.cpu(), torch.zeros(3, dtype=torch.long)) and contrast.index == 3
+    assert torch.equal(labels.cpu(), torch.zeros(6, dtype=torch.long)) and contrast.index == 6
     assert rel_err(contrast.memory, oc.memory) < 1e-6
     og = dict(om.named_parameters())
     for n, p in model.named_parameters():
@@ -154,18 +154,18 @@ def test_project_head_and_api_autograd(pkg, golden):
 
 
 def test_moco_two_step_trace_golden(pkg, golden):
-    """Two full MoCo iterations (tools/train_video_contrast_dis.py:395-454) through MoCoTrainer against the
+    """Three full MoCo iterations (tools/train_video_contrast_dis.py:395-454) through MoCoTrainer against the
     trace recorded with the reference's own model / queue / criterion / optimiser classes."""
     g = golden('steps')
     parity.register_tiny(pkg)
-    cfg = parity.make_cfg(pkg, 'R2P1D10T', 'moco', 32, 16, 8)
+    cfg = parity.make_cfg(pkg, 'R2P1D10T', 'moco', 32, 20, 8)
     tr = pkg.MoCoTrainer(cfg, DEV, use_graph=False, seed=0)
     w = g.group('mo:w:')
     tr.model.load_state_dict(w)
     tr.model_ema.load_state_dict(w)
     tr.contrast.memory.copy_(g.t('mo:mem0'))
-    for it in range(2):
-        out = tr.train_step(g.t('mo:images%d' % it).to(DEV), shuffle_ids=g.t('mo:shuffle%d' % it))
+    for it in range(3):
+        out = tr.train_step(g.x('mo:xspec%d' % it).to(DEV), shuffle_ids=g.t('mo:shuffle%d' % it))
         assert rel_err(out['loss'].reshape(()), g.t('mo:loss%d' % it)) < 1e-3
         assert rel_err(out['logits'], g.t('mo:logits%d' % it)) < 1e-3
         assert rel_err(out['q'], g.t('mo:q%d' % it)) < 1e-3
@@ -176,21 +176,32 @@ def test_moco_two_step_trace_golden(pkg, golden):
     ek = tr.model_ema.state_dict()
     for k, v in g.group('mo:afterk:').items():
         assert rel_err(ek[k], v) < 1e-3, k
-    assert rel_err(tr.contrast.memory, g.t('mo:mem2')) < 1e-3
-    assert int(tr.ptr_dev) == int(g.t('mo:ptr2')) == tr.contrast.index
+    assert rel_err(tr.contrast.memory, g.t('mo:mem3')) < 1e-3
+    assert int(tr.ptr_dev) == int(g.t('mo:ptr3')) == tr.contrast.index == 4
 
 
 @pytest.mark.parametrize('use_graph', [False, True])
 def test_moco_steps_vs_oracle(pkg, use_graph):
-    """4 steps (hipGraph capture kicks in at step 3) incl. queue wrap; params/grads/queue vs the oracle."""
+    """5 MoCo iterations (hipGraph capture kicks in at the 3rd) incl. queue wrap, against the oracle run in
+    fp64, next to the fp32 CPU oracle.  Forward / post-step state: 1e-3 max-norm.  Gradients: distribution
+    bar of parity.check_grad_errors (isolated ReLU-boundary flips are inherent to fp32, see tests/parity.py);
+    the HIP path must not be systematically worse than the fp32 CPU path."""
     parity.register_tiny(pkg)
     gen = torch.Generator().manual_seed(5)
-    imgs = [torch.randn(4, 6, 8, 32, 32, generator=gen) for _ in range(4)]
-    shs = [torch.randperm(4, generator=gen) for _ in range(4)]
-    errs = parity.run_moco_parity(pkg, DEV, 'R2P1D10T', imgs, shs, feat_dim=32, K=12, T=8, use_graph=use_graph)
-    assert errs.pop('ptr') == 0
-    worst = errs.pop('_worst_grad')
-    assert max(errs.values()) < 1e-3, (errs, worst)
+    imgs = [torch.randn(8, 6, 8, 48, 48, generator=gen) for _ in range(5)]
+    shs = [torch.randperm(8, generator=gen) for _ in range(5)]
+    steps = parity.run_moco_parity(pkg, DEV, 'R2P1D10T', imgs, shs, feat_dim=32, K=20, T=8, use_graph=use_graph)
+    med_hip, med_cpu = [], []
+    for it, rec in enumerate(steps):
+        assert rec['post'].pop('ptr') == 0
+        assert max(rec['fwd'].values()) < 1e-3, (it, rec['fwd'])
+        assert max(rec['post'].values()) < 1e-3, (it, rec['post'])
+        parity.check_grad_errors(rec['post_params'], 'step %d updated parameters' % it)
+        parity.check_grad_errors(rec['post_key_params'], 'step %d EMA key parameters' % it)
+        m, _, _ = parity.check_grad_errors(rec['grad_hip'], 'step %d HIP gradients' % it)
+        med_hip.append(m)
+        med_cpu.append(parity._pct(list(rec['grad_cpu'].values()), 0.5))
+    assert sorted(med_hip)[len(med_hip) // 2] < 10 * sorted(med_cpu)[len(med_cpu) // 2] + 1e-5, (med_hip, med_cpu)
 
 
 def test_simsiam_loss_grads_golden(pkg, golden):
@@ -201,7 +212,7 @@ def test_simsiam_loss_grads_golden(pkg, golden):
     assert ema is None
     model.load_state_dict(g.group('ss:w:'))
     model.to(DEV).train()
-    loss = model(g.t('ss:x').to(DEV))
+    loss = model(g.x('ss:xspec').to(DEV))
     assert rel_err(loss, g.t('ss:loss')) < 1e-3
     loss.backward()
     sm = model.model

@@ -63,7 +63,7 @@ def test_r2plus1d_tiny_model_fwd_bwd(golden):
     g = golden('r2p1d_tiny')
     m = oenc.R2Plus1D(10, widen_factor=0.125)
     m.load_state_dict(g.group('r2t:w:'))
-    x = g.t('r2t:x').clone().requires_grad_(True)
+    x = g.x('r2t:xspec').requires_grad_(True)
     m.train()
     y = m(x)
     assert rel_err(y, g.t('r2t:y_train')) < TOL
@@ -82,7 +82,7 @@ def test_r2plus1d_tiny_model_fwd_bwd(golden):
 
 @pytest.mark.parametrize('tag,ctor,strip_fc', [
     ('s3d', lambda: oenc.S3D(), True), ('r18', lambda: oenc.R2Plus1D(18), True),
-    ('r3d18', lambda: oenc.R3D(18, 32, 16), False)])
+    ('r3d18', lambda: oenc.R3D(18, 96, 16), False)])
 def test_full_size_encoders_from_seed(golden, tag, ctor, strip_fc):
     """make_golden.py asserted that the same seed gives the reference's exact weights; here the
     seeded oracle must reproduce the reference's output on the stored input."""
@@ -93,7 +93,7 @@ def test_full_size_encoders_from_seed(golden, tag, ctor, strip_fc):
     if strip_fc:
         m.fc = nn.Identity()
     with torch.no_grad():
-        y = m(g.t(tag + ':x'))
+        y = m(g.x(tag + ':xspec'))
     assert rel_err(y, g.t(tag + ':y_train')) < 1e-4
     if tag == 's3d':
         assert rel_err(m.base[0].bn_s.running_mean, g.t('s3d:rm_base0_bn_s')) < 1e-4
@@ -176,7 +176,7 @@ def test_simsiam_loss_and_grads(golden):
     assert ema is None
     model.load_state_dict(g.group('ss:w:'))
     model.train()
-    loss = model(g.t('ss:x'))
+    loss = model(g.x('ss:xspec'))
     assert rel_err(loss, g.t('ss:loss')) < 1e-4
     loss.backward()
     sm = model.model
@@ -186,14 +186,14 @@ def test_simsiam_loss_and_grads(golden):
 
 
 def test_moco_two_step_trace(golden):
-    """Two full _train_moco iterations (tools/train_video_contrast_dis.py:395-454) against the
+    """Three full _train_moco iterations (queue wraps: K=20, 8 keys per step) (tools/train_video_contrast_dis.py:395-454) against the
     trace produced with the reference's model/queue/criterion/optimiser classes."""
     g = golden('steps')
     oenc.BACKBONES['R2P1D10T'] = lambda: oenc.R2Plus1D(10, widen_factor=0.125)
     model, ema = owrap.create_visual_model('R2P1D10T', 8, 32, 'mlp', 'moco')
     model.load_state_dict(g.group('mo:w:'))
     ema.load_state_dict(g.group('mo:w:'))
-    contrast = omoco.RGBMoCo(32, K=16, T=0.07)
+    contrast = omoco.RGBMoCo(32, K=20, T=0.07)
     contrast.memory.copy_(g.t('mo:mem0'))
     opt = omoco.make_optimizer(model, 0.06, 0.9, 5e-4)
     # make_lr_scheduler runs before the first iteration (tools/...dis.py:117): epoch-0 warm-up factor applies
@@ -207,8 +207,8 @@ def test_moco_two_step_trace(golden):
     model.train()
     omoco.set_key_encoder_mode(ema)
     crit = omoco.NCESoftmaxLoss()
-    for it in range(2):
-        r = omoco.moco_train_step(model, ema, contrast, crit, opt, g.t('mo:images%d' % it), 0.999,
+    for it in range(3):
+        r = omoco.moco_train_step(model, ema, contrast, crit, opt, g.x('mo:xspec%d' % it), 0.999,
                                   shuffle_ids=g.t('mo:shuffle%d' % it))
         assert rel_err(r['loss'], g.t('mo:loss%d' % it)) < 1e-4
         assert rel_err(r['logits'], g.t('mo:logits%d' % it)) < 1e-3
@@ -220,8 +220,8 @@ def test_moco_two_step_trace(golden):
     ek = ema.state_dict()
     for k, v in g.group('mo:afterk:').items():
         assert rel_err(ek[k].float(), v.float()) < 1e-3, k
-    assert rel_err(contrast.memory, g.t('mo:mem2')) < 1e-3
-    assert contrast.index == int(g.t('mo:ptr2'))
+    assert rel_err(contrast.memory, g.t('mo:mem3')) < 1e-3
+    assert contrast.index == int(g.t('mo:ptr3')) == 4
 
 
 def test_lr_schedule(golden):

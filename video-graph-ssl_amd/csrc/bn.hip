@@ -24,13 +24,15 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
     long long N, long long C, long long SP, long long zs, int P, float* __restrict__ out0,
     float* __restrict__ out1) {
-  __shared__ float sh[4];
+  __shared__ double sh[4];
   const int c = blockIdx.y, part = blockIdx.x;
   const long long M = N * SP;
   const long long per = (M + P - 1) / P;
   const long long lo = part * per;
   long long hi = lo + per; if (hi > M) hi = M;
-  float s0 = 0.f, s1 = 0.f;
+  // fp64 accumulators: these sums cancel heavily (a BN output gradient is nearly zero-mean), and ATen's CPU
+  // batch norm accumulates in double too.  The kernel stays HBM-bound (3 DP ops per element).
+  double s0 = 0.0, s1 = 0.0;
   float mu = 0.f, is = 0.f;
   if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
   const long long i0 = lo + threadIdx.x;
@@ -41,20 +43,20 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     else { n = i / SP; sp = i - n * SP; }
     const long long idx = (n * C + c) * SP + sp;
     if (MODE == 0) {
-      const float v = a[idx];
+      const double v = (double)a[idx];
       s0 += v; s1 += v * v;
     } else {
       const long long zidx = n * zs + c * SP + sp;       // dz / z may be channel slices of a concat buffer
       float dz = a[zidx];
       if (relu && !(z[zidx] > 0.f)) dz = 0.f;
-      s0 += dz; s1 += dz * ((x[idx] - mu) * is);
+      s0 += (double)dz; s1 += (double)dz * (double)((x[idx] - mu) * is);
     }
   }
-  s0 = gca_block_sum256(s0, sh);
-  s1 = gca_block_sum256(s1, sh);
+  s0 = gca_block_sum256_d(s0, sh);
+  s1 = gca_block_sum256_d(s1, sh);
   if (threadIdx.x == 0) {
-    out0[(long long)c * P + part] = s0;
-    out1[(long long)c * P + part] = s1;
+    out0[(long long)c * P + part] = (float)s0;
+    out1[(long long)c * P + part] = (float)s1;
   }
 }
 

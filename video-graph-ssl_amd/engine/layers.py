@@ -181,6 +181,8 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
                 dres, racc = residual.grad_buffer()
             dy = ops.bn_bwd(zv.grad, z, y, bn.weight.data, mean, invstd, relu, N, K, SP,
                             _grad_of(bn.weight), _grad_of(bn.bias), dres, bool(racc))
+            if DEBUG_GRADS is not None:          # diagnostics only: gradient wrt the conv output, per BN module
+                DEBUG_GRADS[id(bn)] = (zv.grad.clone(), dy.clone())
             zv.grad = None
             ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
             if xv.needs_grad:
@@ -188,6 +190,9 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
                 ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
         tape.record(back)
     return zv
+
+
+DEBUG_GRADS = None
 
 
 def f_conv(tape, conv, xv):
