@@ -51,6 +51,7 @@ def parse():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--layer-table', action='store_true', help='log per-layer conv kernel timings to stderr')
     return ap.parse_args()
 
 
@@ -135,13 +136,18 @@ def kernel_timing(pkg, trainer, args):
         dw = torch.zeros_like(w)
         dx = torch.empty(shp, device='cuda')
         t = ev_time_ms(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5, 1)
+        t_f, t_d = t, None
         add('conv_igemm_kernel<%d,128,2,2,0>' % _bm(K), t, flops, 2)            # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
             unit = tuple(m.stride) == (1, 1, 1)
-            t = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
+            t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
             add('conv_igemm_kernel<%d,128,2,2,%d>' % (_bm(shp[1]), 0 if unit else 1), t, flops, 1)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         add('conv_wgrad_kernel<%d,%d>' % (_bm(K), _bm(shp[1] * taps)), t, flops, 1)
+        if args.layer_table:
+            log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
+                % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, t_f, flops / 1e9 / t_f,
+                   ('%7.3f ms %6.1f TF' % (t_d, flops / 1e9 / t_d)) if t_d else '      --       ', t, flops / 1e9 / t))
         del x, dy, dx
     table = {k: dict(ms_per_step=round(v[0], 4), gflop_per_step=round(v[1] / 1e9, 2), launches_per_step=v[2],
                      tflops=round((v[1] / 1e12) / (v[0] / 1e3), 3)) for k, v in sym.items()}

@@ -43,11 +43,18 @@ typedef struct {
   int32_t kd, kh, kw;          /* kernel                        */
   int32_t sd, sh, sw;          /* stride                        */
   int32_t pd, ph, pw;          /* zero padding                  */
-  int32_t OD, OH, OW;          /* output spatial (caller-computed, checked) */
+  int32_t OD, OH, OW;          /* output spatial (caller-computed, checked).  Each tensor must hold
+                                  < 2^30 elements (32-bit byte offsets inside the kernels). */
   int64_t x_batch_stride;      /* elements between consecutive clips of x; 0 = C*D*H*W (contiguous).
                                   Lets the two views of a (b,6,T,H,W) batch be read in place
                                   (tools/train_video_contrast_dis.py:404 torch.chunk on dim 1).
                                   Honoured by gca_conv_fwd and gca_conv_wgrad; dgrad needs 0. */
+  /* Launch tuning (0 = built-in heuristic).  The host measures a few candidates per geometry once
+   * -- the reference does the same through cudnn.benchmark = True, tools/train_video_contrast_dis.py:50 --
+   * and pins the winner here.  Results are deterministic for a fixed setting. */
+  int32_t tune_fwd_bm, tune_fwd_splits;       /* block-tile height (64 | 128), split-K factor */
+  int32_t tune_dgrad_bm, tune_dgrad_splits;
+  int32_t tune_wgrad_splits, tune_reserved;
 } gca_conv_geom;
 
 /* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward
@@ -66,12 +73,20 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_
  * partial sums / sums of squares of y (training-mode BatchNorm statistics, fused):
  * layout [K][P], P = gca_conv_fwd_stat_parts(g). */
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
+/* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad):
+ * out4 = {block-tile height, split-K factor, gather mode (0 linear, 1 divide), tap-mask fast path}. */
+int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
+/* Layers whose output grid cannot fill the 256 CUs split the reduction over workgroups; the fp32
+ * partial slabs live in `ws` (gca_conv_fwd_ws_bytes / gca_conv_dgrad_ws_bytes; 0 = not needed, ws may
+ * then be NULL) and are summed in a fixed order (deterministic). */
+int64_t gca_conv_fwd_ws_bytes(const gca_conv_geom* g);
 int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, const int32_t* table,
-                 const float* bias, float* y, float* stat_sum, float* stat_sq, void* stream);
+                 const float* bias, float* y, float* stat_sum, float* stat_sq, void* ws, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  `wpack`/`table` from which=1.  accumulate != 0 adds into dx. */
+int64_t gca_conv_dgrad_ws_bytes(const gca_conv_geom* g);
 int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, const int32_t* table,
-                   float* dx, int accumulate, void* stream);
+                   float* dx, int accumulate, void* ws, void* stream);
 
 /* dw (+)= sum_{n,o} dy[n,k,o] * x[n,c,o*s-p+tap].  `table` from which=2.  Split-K partial slabs go
  * to `ws` (gca_conv_wgrad_ws_bytes) and are reduced deterministically. */

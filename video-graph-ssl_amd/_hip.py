@@ -28,7 +28,9 @@ c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, 
 
 class ConvGeom(C.Structure):
     _fields_ = [(n, c_i32) for n in ('N', 'C', 'D', 'H', 'W', 'K', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
-                                     'pd', 'ph', 'pw', 'OD', 'OH', 'OW')] + [('x_batch_stride', c_i64)]
+                                     'pd', 'ph', 'pw', 'OD', 'OH', 'OW')] + [('x_batch_stride', c_i64)] + \
+               [(n, c_i32) for n in ('tune_fwd_bm', 'tune_fwd_splits', 'tune_dgrad_bm', 'tune_dgrad_splits',
+                                     'tune_wgrad_splits', 'tune_reserved')]
 
 
 class PoolGeom(C.Structure):
@@ -45,8 +47,11 @@ SIGNATURES = {
     'gca_conv_table_rows': (c_i64, [_GP, c_i32]),
     'gca_conv_table_build_host': (c_i32, [_GP, c_i32, c_vp]),
     'gca_conv_fwd_stat_parts': (c_i64, [_GP]),
-    'gca_conv_fwd': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'gca_conv_dgrad': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'gca_conv_kernel_cfg': (c_i32, [_GP, c_i32, c_vp]),
+    'gca_conv_fwd_ws_bytes': (c_i64, [_GP]),
+    'gca_conv_fwd': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'gca_conv_dgrad_ws_bytes': (c_i64, [_GP]),
+    'gca_conv_dgrad': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     'gca_conv_wgrad_ws_bytes': (c_i64, [_GP]),
     'gca_conv_wgrad': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     'gca_bias_grad': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),

@@ -6,6 +6,7 @@ workspace sizes) is cached per geometry.
 """
 import ctypes as C
 import functools
+import os
 
 import torch
 
@@ -42,8 +43,23 @@ WS = _Workspace()
 
 
 # ----------------------------------------------------------------------------- convolution
+AUTOTUNE = os.environ.get('GCA_AUTOTUNE', '1') != '0'
+
+
+def _time_ms(fn, reps=3):
+    fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps
+
+
 class ConvPlan:
-    """Everything geometry-dependent about one conv: the ABI struct, device gather tables."""
+    """Everything geometry-dependent about one conv: the ABI struct, device gather tables, and the launch
+    configuration pinned by a one-off measurement (the role cudnn.benchmark plays in the reference)."""
 
     def __init__(self, N, Cin, D, Hh, W, K, k, s, p, device, x_batch_stride=0):
         kd, kh, kw = _t3(k)
@@ -55,12 +71,20 @@ class ConvPlan:
         self.in_shape = (N, Cin, D, Hh, W)
         self.out_shape = (N, K, OD, OH, OW)
         self.device = device
+        self.taps = kd * kh * kw
         self._tables = {}
-        self.parts = H.lib.gca_conv_fwd_stat_parts(self.gp)
-        if self.parts < 0:
+        self.tuned = [not AUTOTUNE] * 3
+        if H.lib.gca_conv_fwd_stat_parts(self.gp) < 0:
             raise ValueError('unsupported conv geometry %r' % ((N, Cin, D, Hh, W, K, k, s, p),))
         self.pack_elems = [H.lib.gca_conv_pack_elems(self.gp, 0), H.lib.gca_conv_pack_elems(self.gp, 1)]
+        self.refresh()
+
+    def refresh(self):
+        """Sizes that depend on the launch configuration."""
+        self.parts = H.lib.gca_conv_fwd_stat_parts(self.gp)
         self.wgrad_ws = H.lib.gca_conv_wgrad_ws_bytes(self.gp)
+        self.fwd_ws = H.lib.gca_conv_fwd_ws_bytes(self.gp)
+        self.dgrad_ws = H.lib.gca_conv_dgrad_ws_bytes(self.gp) if self.g.x_batch_stride == 0 else 0
 
     def table(self, which):
         t = self._tables.get(which)
@@ -71,6 +95,66 @@ class ConvPlan:
             t = host.to(self.device)
             self._tables[which] = t
         return t
+
+    def cfg(self, which):
+        out = (C.c_int32 * 4)()
+        H.call('gca_conv_kernel_cfg', self.gp, which, out)
+        return tuple(out)
+
+    # ---- one-off launch tuning ------------------------------------------------------------
+    def _igemm_candidates(self, M, Ntot, kred):
+        nk = -(-kred // 16)
+        tn = -(-Ntot // 128)
+        cands = []
+        for bm in (64, 128):
+            if bm == 128 and M <= 64:
+                continue
+            tiles = -(-M // bm) * tn
+            for s in (1, 2, 3, 4, 6, 8, 12, 16):
+                if s > 1 and (tiles >= 1024 or nk // s < 4 or s * M * Ntot * 4 > (96 << 20)):
+                    continue
+                cands.append((bm, s))
+        return cands
+
+    def tune(self, which, run):
+        """Measure the candidate launch configurations of pass `which` (0 fwd, 1 dgrad, 2 wgrad) with `run`
+        (a closure launching that pass on real operands) and pin the fastest."""
+        if self.tuned[which] or torch.cuda.is_current_stream_capturing():
+            return
+        self.tuned[which] = True
+        g = self.g
+        N, K, OD, OH, OW = self.out_shape
+        if which == 0:
+            cands = self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)
+        elif which == 1:
+            cands = self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)
+        else:
+            kt = -(-(N * OD * OH * OW) // 32)
+            base = max(1, min(kt // 4, 1024 // max(1, (-(-K // 128)) * (-(-(g.C * self.taps) // 128)))))
+            cands = sorted(set(max(1, min(kt, int(base * f))) for f in (0.25, 0.5, 1, 2, 4)))
+        best, best_t = None, None
+        for c in cands:
+            if which == 0:
+                g.tune_fwd_bm, g.tune_fwd_splits = c
+            elif which == 1:
+                g.tune_dgrad_bm, g.tune_dgrad_splits = c
+            else:
+                g.tune_wgrad_splits = c
+            self.refresh()
+            try:
+                t = _time_ms(run)
+            except RuntimeError:
+                continue
+            if best_t is None or t < best_t:
+                best, best_t = c, t
+        if best is not None:
+            if which == 0:
+                g.tune_fwd_bm, g.tune_fwd_splits = best
+            elif which == 1:
+                g.tune_dgrad_bm, g.tune_dgrad_splits = best
+            else:
+                g.tune_wgrad_splits = best
+        self.refresh()
 
 
 @functools.lru_cache(maxsize=None)
@@ -91,29 +175,52 @@ def conv_pack(plan, which, w, out=None):
     return out
 
 
+def _conv_fwd_launch(plan, x, wpack, bias, y, ss, sq):
+    ws = WS.get(plan.fwd_ws, x.device) if plan.fwd_ws else None
+    H.call('gca_conv_fwd', plan.gp, ptr(x), ptr(wpack), ptr(plan.table(0)), ptr(bias), ptr(y), ptr(ss), ptr(sq),
+           ptr(ws), stream())
+
+
 def conv_fwd(plan, x, wpack, bias=None, stats=False):
     """-> y [, (stat_sum, stat_sq)]  with stat layout [K][plan.parts]."""
     y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    if not plan.tuned[0]:
+        plan.tune(0, lambda: _conv_fwd_launch(plan, x, wpack, bias, y, None, None))
     ss = sq = None
     if stats:
         ss = torch.empty((plan.g.K, plan.parts), dtype=F32, device=x.device)
         sq = torch.empty((plan.g.K, plan.parts), dtype=F32, device=x.device)
-    H.call('gca_conv_fwd', plan.gp, ptr(x), ptr(wpack), ptr(plan.table(0)), ptr(bias), ptr(y), ptr(ss), ptr(sq),
-           stream())
+    _conv_fwd_launch(plan, x, wpack, bias, y, ss, sq)
     return (y, (ss, sq)) if stats else y
+
+
+def _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate):
+    ws = WS.get(plan.dgrad_ws, dy.device) if plan.dgrad_ws else None
+    H.call('gca_conv_dgrad', plan.gp, ptr(dy), ptr(wpack_t), ptr(plan.table(1)), ptr(dx), int(accumulate), ptr(ws),
+           stream())
 
 
 def conv_dgrad(plan, dy, wpack_t, dx=None, accumulate=False):
     if dx is None:
         dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
         accumulate = False
-    H.call('gca_conv_dgrad', plan.gp, ptr(dy), ptr(wpack_t), ptr(plan.table(1)), ptr(dx), int(accumulate), stream())
+    if not plan.tuned[1]:
+        scratch = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        plan.tune(1, lambda: _conv_dgrad_launch(plan, dy, wpack_t, scratch, False))
+    _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate)
     return dx
 
 
-def conv_wgrad(plan, x, dy, dw, accumulate=True):
+def _conv_wgrad_launch(plan, x, dy, dw, accumulate):
     ws = WS.get(plan.wgrad_ws, x.device)
     H.call('gca_conv_wgrad', plan.gp, ptr(x), ptr(dy), ptr(plan.table(2)), ptr(dw), int(accumulate), ptr(ws), stream())
+
+
+def conv_wgrad(plan, x, dy, dw, accumulate=True):
+    if not plan.tuned[2]:
+        scratch = torch.empty_like(dw)
+        plan.tune(2, lambda: _conv_wgrad_launch(plan, x, dy, scratch, False))
+    _conv_wgrad_launch(plan, x, dy, dw, accumulate)
     return dw
 
 
