@@ -102,7 +102,7 @@ def conv_layers_of(model, x_shape, pkg):
 
 
 def _bm(dk):
-    """Mirror of use_bm64() in csrc/conv3d.hip: block-tile height the launcher picks for `dk` GEMM rows."""
+    """Mirror of the wgrad tile rule in csrc/conv3d.hip (wgrad_plan): tile edge picked for `dk` GEMM rows/cols."""
     if dk <= 64:
         return 64
     t128, t64 = -(-dk // 128) * 128, -(-dk // 64) * 64
@@ -137,16 +137,18 @@ def kernel_timing(pkg, trainer, args):
         dx = torch.empty(shp, device='cuda')
         t = ev_time_ms(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5, 1)
         t_f, t_d = t, None
-        add('conv_igemm_kernel<%d,128,2,2,0>' % _bm(K), t, flops, 2)            # key + query forward
+        c0 = plan.cfg(0)
+        add('conv_igemm_kernel<%d,2,2,%d,%s>' % (c0[0], c0[2], 'true' if c0[3] else 'false'), t, flops, 2)   # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
-            unit = tuple(m.stride) == (1, 1, 1)
             t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
-            add('conv_igemm_kernel<%d,128,2,2,%d>' % (_bm(shp[1]), 0 if unit else 1), t, flops, 1)
+            c1 = plan.cfg(1)
+            add('conv_igemm_kernel<%d,2,2,%d,%s>' % (c1[0], c1[2], 'true' if c1[3] else 'false'), t, flops, 1)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         add('conv_wgrad_kernel<%d,%d>' % (_bm(K), _bm(shp[1] * taps)), t, flops, 1)
         if args.layer_table:
-            log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
-                % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, t_f, flops / 1e9 / t_f,
+            log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
+                % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, plan.cfg(0)[:2], plan.cfg(1)[:2] if i > 0 else '-',
+                   plan.g.tune_wgrad_splits, t_f, flops / 1e9 / t_f,
                    ('%7.3f ms %6.1f TF' % (t_d, flops / 1e9 / t_d)) if t_d else '      --       ', t, flops / 1e9 / t))
         del x, dy, dx
     table = {k: dict(ms_per_step=round(v[0], 4), gflop_per_step=round(v[1] / 1e9, 2), launches_per_step=v[2],

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 
   float breg[B_PER];
   float4 areg[A_F4];
+  unsigned bmask = 0;
 
   auto load_tiles = [&](int kt) {
     // A: packed weights [Kpad][Mpad], rows kt*BK.., cols tileM*BM..
@@ -141,19 +142,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     int2 e[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) e[i] = trow[i];
+    bmask = 0;      // validity bits; applied when the tile is written to LDS, so the loads stay in flight
     if (FAST) {
-      int idx[B_PER]; bool ok[B_PER];
+      int idx[B_PER];
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int tap6 = (e[i].y >> 25) & 63;            // 63 = padded row, never valid
         const unsigned m = tap6 < 32 ? mlo : mhi;
-        ok[i] = (m >> (tap6 & 31)) & 1u;
-        idx[i] = ok[i] ? colbase + e[i].x : 0;
+        const unsigned ok = (m >> (tap6 & 31)) & 1u;
+        bmask |= ok << i;
+        idx[i] = ok ? colbase + e[i].x : 0;
       }
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) breg[i] = src[(unsigned)idx[i]];
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) breg[i] = ok[i] ? breg[i] : 0.f;
     } else {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
           ok = ok & (qd < (unsigned)p.SD) & (qh < (unsigned)p.SH) & (qw < (unsigned)p.SW);
           idx = colbase + off + (int)qd * SHW + (int)qh * p.SW + (int)qw;
         }
-        const float v = src[(unsigned)(ok ? idx : 0)];
-        breg[i] = ok ? v : 0.f;
+        bmask |= (unsigned)ok << i;
+        breg[i] = src[(unsigned)(ok ? idx : 0)];
       }
     }
   };
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
       *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg[i];
     }
 #pragma unroll
-    for (int i = 0; i < B_PER; ++i) Bs[buf][r0 + i][col] = breg[i];
+    for (int i = 0; i < B_PER; ++i) Bs[buf][r0 + i][col] = ((bmask >> i) & 1u) ? breg[i] : 0.f;
   };
 
   f32x16 acc[TM][TN];
@@ -258,15 +259,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     float* d0 = dst + ((long long)img * p.DK) * OSP + sp;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float old[16];
+      if (p.accumulate) {                       // all 16 read-modify-write loads in flight together
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          old[r] = (nv && m < p.DK) ? d0[(long long)m * OSP] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (nv && m < p.DK) {
           float v = acc[i][j][r];
           if (bias) v += bias[m];
-          float* d = d0 + (long long)m * OSP;
-          if (p.accumulate) v += *d;
-          *d = v;
+          if (p.accumulate) v += old[r];
+          d0[(long long)m * OSP] = v;
         }
       }
     }
@@ -378,6 +386,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const int lh = lane >> 5, ll = lane & 31;
 
   float areg[A_PER], breg[B_PER];
+  unsigned amask = 0, bmask = 0;     // validity bits, applied at the LDS store so the loads stay in flight
   auto load_tiles = [&](int kt) {
     const long long kp = (long long)kt * WBK + kl;
     const bool kv = kp < p.Ktot;
@@ -394,10 +403,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       const int m = tileM * BM + g + 8 * i;
       aidx[i] = (kv & (m < p.K)) ? abase + m * OSP : -1;
     }
+    amask = 0;
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) areg[i] = dy[(unsigned)(aidx[i] < 0 ? 0 : aidx[i])];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) areg[i] = aidx[i] < 0 ? 0.f : areg[i];
+    for (int i = 0; i < A_PER; ++i) { amask |= (unsigned)(aidx[i] >= 0) << i; areg[i] = dy[(unsigned)(aidx[i] < 0 ? 0 : aidx[i])]; }
     // B: X window element for (c, tap) = table row n'
     const int id0 = od * p.sd - p.pd, ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
     const int bbase = (int)((long long)img * p.x_nstride) + id0 * HW + ih0 * p.W + iw0;
@@ -413,16 +421,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.W);
       bidx[j] = ok ? bbase + off : -1;
     }
+    bmask = 0;
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) breg[j] = x[(unsigned)(bidx[j] < 0 ? 0 : bidx[j])];
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) breg[j] = bidx[j] < 0 ? 0.f : breg[j];
+    for (int j = 0; j < B_PER; ++j) { bmask |= (unsigned)(bidx[j] >= 0) << j; breg[j] = x[(unsigned)(bidx[j] < 0 ? 0 : bidx[j])]; }
   };
   auto store_tiles = [&]() {
 #pragma unroll
-    for (int i = 0; i < A_PER; ++i) As[kl * LDA + g + 8 * i] = areg[i];
+    for (int i = 0; i < A_PER; ++i) As[kl * LDA + g + 8 * i] = ((amask >> i) & 1u) ? areg[i] : 0.f;
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) Bs[kl * LDB + g + 8 * j] = breg[j];
+    for (int j = 0; j < B_PER; ++j) Bs[kl * LDB + g + 8 * j] = ((bmask >> j) & 1u) ? breg[j] : 0.f;
   };
 
   if (kt0 < kt1) load_tiles(kt0);
