@@ -109,6 +109,12 @@ def _bm(dk):
     return 64 if ((t128 - dk) * 4 > t128 and t64 < t128) else 128
 
 
+def _sym(c):
+    """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<9}."""
+    vec, fast = (c[3] >> 9) & 1, (c[3] >> 8) & 1
+    return 'conv_igemm_kernel<%d,%d,%s,%s>' % (c[0] // 32, c[1], 'true' if fast else 'false', 'true' if vec else 'false')
+
+
 def kernel_timing(pkg, trainer, args):
     """Time every conv launch of one training step (each conv layer's forward x2 [key+query], dgrad, wgrad)
     with HIP events on the launch stream and aggregate per KERNEL SYMBOL (what rocprofv3 --stats reports):
@@ -138,16 +144,16 @@ def kernel_timing(pkg, trainer, args):
         t = ev_time_ms(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5, 1)
         t_f, t_d = t, None
         c0 = plan.cfg(0)
-        add('conv_igemm_kernel<%d,2,2,%d,%s>' % (c0[0], c0[2], 'true' if c0[3] else 'false'), t, flops, 2)   # key + query forward
+        add(_sym(c0), t, flops, 2)   # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
             t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
             c1 = plan.cfg(1)
-            add('conv_igemm_kernel<%d,2,2,%d,%s>' % (c1[0], c1[2], 'true' if c1[3] else 'false'), t, flops, 1)
+            add(_sym(c1), t, flops, 1)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         add('conv_wgrad_kernel<%d,%d>' % (_bm(K), _bm(shp[1] * taps)), t, flops, 1)
         if args.layer_table:
             log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
-                % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, plan.cfg(0)[:2], plan.cfg(1)[:2] if i > 0 else '-',
+                % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, plan.cfg(0)[:3], plan.cfg(1)[:3] if i > 0 else '-',
                    plan.g.tune_wgrad_splits, t_f, flops / 1e9 / t_f,
                    ('%7.3f ms %6.1f TF' % (t_d, flops / 1e9 / t_d)) if t_d else '      --       ', t, flops / 1e9 / t))
         del x, dy, dx

@@ -52,7 +52,8 @@ typedef struct {
   /* Launch tuning (0 = built-in heuristic).  The host measures a few candidates per geometry once
    * -- the reference does the same through cudnn.benchmark = True, tools/train_video_contrast_dis.py:50 --
    * and pins the winner here.  Results are deterministic for a fixed setting. */
-  int32_t tune_fwd_bm, tune_fwd_splits;       /* block-tile height (64 | 128), split-K factor */
+  int32_t tune_fwd_bm, tune_fwd_splits;       /* tile rows 32..160 (x128 columns), | 1024 = x256 columns with float4
+                                                 gathers (pointwise-in-space convs only); split-K factor */
   int32_t tune_dgrad_bm, tune_dgrad_splits;
   int32_t tune_wgrad_splits, tune_reserved;
 } gca_conv_geom;
@@ -73,8 +74,8 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_
  * partial sums / sums of squares of y (training-mode BatchNorm statistics, fused):
  * layout [K][P], P = gca_conv_fwd_stat_parts(g). */
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
-/* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad):
- * out4 = {block-tile height, split-K factor, gather mode (0 linear, 1 divide), tap-mask fast path}. */
+/* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad), first non-empty class:
+ * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask<<8 | float4-gather<<9}. */
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
 /* Layers whose output grid cannot fill the 256 CUs split the reduction over workgroups; the fp32
  * partial slabs live in `ws` (gca_conv_fwd_ws_bytes / gca_conv_dgrad_ws_bytes; 0 = not needed, ws may

@@ -65,6 +65,45 @@ def test_conv_random_vs_aten(ops, shape, K, k, s, p):
     assert rel_err(dw, wr.grad) < 1e-5
 
 
+@pytest.mark.parametrize('shape,K,k,s,p', [
+    ((3, 40, 5, 8, 8), 150, (3, 1, 1), (1, 1, 1), (1, 0, 0)),       # pointwise in space: float4-gather variants
+    ((2, 24, 6, 8, 8), 70, (3, 1, 1), (2, 1, 1), (1, 0, 0)),        # ... with temporal stride (dgrad classes)
+    ((2, 20, 3, 12, 12), 100, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # spatial window, strided (4 dgrad classes)
+    ((2, 33, 1, 1, 1), 170, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # Linear
+])
+def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
+    """Force every tile height (32..160), the 256-column float4 variant, and split-K factors through the
+    tune_* fields: all must give the same convolution (the autotuner may pick any of them)."""
+    torch.manual_seed(0)
+    x = torch.randn(shape)
+    w = torch.randn((K, shape[1]) + tuple(k)) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, s, p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    plan = ops.ConvPlan(*shape, K, k, s, p, DEV)
+    plan.tuned = [True, True, True]
+    seen = set()
+    for code in (32, 64, 96, 128, 160, 1024 + 32, 1024 + 64, 1024 + 128):
+        for sp in (1, 3):
+            plan.g.tune_fwd_bm = plan.g.tune_dgrad_bm = code
+            plan.g.tune_fwd_splits = plan.g.tune_dgrad_splits = sp
+            plan.g.tune_wgrad_splits = sp
+            plan.refresh()
+            seen.add((plan.cfg(0), plan.cfg(1)))
+            y, (ss, sq) = ops.conv_fwd(plan, xd, ops.conv_pack(plan, 0, wd), None, stats=True)
+            dx = ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd))
+            dw = torch.zeros_like(wd)
+            ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
+            assert rel_err(y, yr) < 1e-5, (code, sp, plan.cfg(0))
+            assert rel_err(dx, xr.grad) < 1e-5, (code, sp, plan.cfg(1))
+            assert rel_err(dw, wr.grad) < 1e-5, (code, sp)
+            assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4
+            assert rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-4
+    assert len(seen) >= 8
+
+
 def test_conv_batch_stride_views(ops):
     """The two views of a (b,6,T,H,W) batch are read in place (tools/...dis.py:404)."""
     torch.manual_seed(1)

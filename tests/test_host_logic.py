@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     for name in declared:
         assert getattr(pkg._hip.lib, name) is not None
-    assert pkg._hip.lib.gca_version() >= 2
+    assert pkg._hip.lib.gca_version() >= 3
 
 
 def test_product_path_refuses_cpu_tensors(pkg):
@@ -37,7 +37,7 @@ def test_geometry_validation_without_gpu(pkg):
     import ctypes as C
     good = H.ConvGeom(2, 3, 4, 8, 8, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, 4, 8, 8, 0)
     assert H.lib.gca_conv_pack_elems(C.byref(good), 0) == 32 * 64          # K = 27 -> 32, M = 5 -> 64
-    assert H.lib.gca_conv_table_rows(C.byref(good), 1) == 48               # 5 * 9 = 45 -> 48
+    assert H.lib.gca_conv_table_rows(C.byref(good), 1) == 48 + 32          # 5 * 9 = 45 -> 48 rows + tap-delta table
     bad = H.ConvGeom(2, 3, 4, 8, 8, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, 4, 8, 7, 0)   # wrong OW
     assert H.lib.gca_conv_pack_elems(C.byref(bad), 0) == -1
     rows = H.lib.gca_conv_table_rows(C.byref(good), 0)

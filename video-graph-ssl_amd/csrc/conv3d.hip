@@ -3,138 +3,146 @@
 //
 //   forward : Y[n,ko,o]   = sum_{c,tap} W[ko,c,tap] * X[n,c,o*s-p+tap]        M=Ko   N=n*o      K=c*tap
 //   dgrad   : dX[n,c,i]   = sum_{ko,tap} W[ko,c,tap] * dY[n,ko,(i+p-tap)/s]   M=C    N=n*i      K=ko*tap
-//   wgrad   : dW[ko,c,tap]= sum_{n,o}  dY[n,ko,o] * X[n,c,o*s-p+tap]          M=Ko   N=c*tap    K=n*o (split)
+//   (wgrad lives in conv3d_wgrad.hip)
 //
 // Activations stay NCDHW: for a fixed GEMM-K row (channel, tap) the GEMM-N direction is the
-// W axis of the image, so a wave's 64 lanes read 64 consecutive floats (coalesced along W).
+// W axis of the image, so a wave's 64 lanes read consecutive floats (coalesced along W).
 // Nothing is materialised: the im2col window is gathered straight into LDS through a small
 // per-row table (element offset + tap id).  Window bounds are resolved ONCE per thread into a
-// 64-bit tap-validity mask (its GEMM column is fixed for the whole K loop), so the gather in the
-// hot loop is: bit test, index select, one dword load -- no branches, no per-element compares.
-// The weight operand is pre-packed k-major and zero padded (gca_conv_pack) so its tile loads are
-// unpredicated float4.  Layers whose output grid cannot fill 256 CUs split the K loop over
-// workgroups (fp32 partial slabs + a deterministic finishing pass that also emits the BN sums).
+// 64-bit tap-validity mask (its GEMM columns are fixed for the whole K loop), so the gather in the
+// hot loop is: bit test, index select, load -- no branches, no per-element compares.
+//
+// Every pass is expressed as one or more LINEAR gather problems ("classes"):
+//   forward            one class:  src = q*stride - pad + tap
+//   unit-stride dgrad  one class:  src = q + pad - tap
+//   strided dgrad      one class per output-position residue rho (i = s*q + rho): only the taps with
+//                      (rho + pad - tap) % s == 0 contribute and src = q + (rho + pad - tap)/s, so no
+//                      MFMA work is spent on structurally-zero products and nothing is divided in the loop.
+// Convolutions that are pointwise in space (kh = kw = 1: the (k,1,1) temporal convs and 1x1x1, 44 % of
+// R(2+1)D's FLOPs) take the VEC variant: a GEMM-K row is one contiguous run of the image, gathered with
+// float4 loads into a 64 x 256 tile.  The weight operand is pre-packed k-major and zero padded
+// (gca_conv_pack) so its tile loads are unpredicated float4.  Problems whose tile grid cannot fill
+// 256 CUs split the K loop over workgroups (fp32 partial slabs + a deterministic finishing pass that
+// also emits the BatchNorm sums).
 //
 // Reference call sites replaced: every nn.Conv3d / nn.Linear on the path (see include/gca_hip.h).
-#include "gca_common.h"
+#include "conv_common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include <cstdlib>
+#include <vector>
+
+using namespace gca_conv;
 
 namespace {
 
-constexpr int BK = 16;          // GEMM-K tile of the forward/dgrad kernels
-constexpr int BN = 128;         // GEMM-N (spatial) tile of the forward/dgrad kernels
-constexpr int WBK = 32;         // GEMM-K (spatial) tile of the wgrad kernel
-constexpr int MPAD = 64;        // packed weights: M padded to this
-constexpr int TABLE_PAD_W = 128;
-constexpr int FAST_MAX_TAPS = 62;
-constexpr int NUM_CU = 256;
-
-// row table entry: x = element offset; y = dd | dh<<8 | dw<<16 (signed bytes) | valid<<24 | tap6<<25
-__device__ __forceinline__ void decode_row(int2 e, int& off, int& dd, int& dh, int& dw, int& valid) {
-  off = e.x;
-  dd = (e.y << 24) >> 24;
-  dh = (e.y << 16) >> 24;
-  dw = (e.y << 8) >> 24;
-  valid = (e.y >> 24) & 1;
-}
-
 struct IgemmParams {
-  int NB;                  // batch
   int SC, SD, SH, SW;      // gathered (source) tensor: channels + spatial dims
   int DK;                  // destination channels (GEMM M, un-padded)
-  int OD, OH, OW;          // destination spatial dims (GEMM N = NB*OD*OH*OW)
-  int m_d, m_h, m_w;       // MODE 0: src = dst*m + o + delta ; MODE 1: src = (dst + o + delta)/m
+  int QD, QH, QW;          // iteration sub-grid (GEMM N = NB*QD*QH*QW)
+  int DD, DH, DW;          // destination tensor spatial dims
+  int dm_d, dm_h, dm_w;    // destination position = q*dm + do
+  int do_d, do_h, do_w;
+  int m_d, m_h, m_w;       // source position = q*m + o + tap delta
   int o_d, o_h, o_w;
-  int kd, kh, kw, tap_sign;// tap enumeration for the per-thread validity mask (delta = sign * (a,b,c))
+  int ntaps;               // taps of this class (FAST: <= 62)
   int Kpad, Mpad;
   int tilesM, tilesN;
   int splits, kt_per_split;
   int P;                   // stat partials per channel
-  int force_bm, force_splits;   // host-side tuning overrides (0 = heuristic)
   int chk;                 // bit0: test D, bit1: test H, bit2: test W
   int accumulate;
   long long Ntot;
   long long src_nstride;   // elements between consecutive images of the gathered tensor
+  unsigned src_bytes;      // extent of the gathered tensor for the buffer resource (range check)
 };
 
 // ---------------------------------------------------------------------------------------------
-// forward / dgrad implicit GEMM.  256 threads = 4 waves laid out WM x WN; each wave owns
-// (BM/WM) x (BN/WN) of the block tile as TM x TN MFMA 32x32 tiles.
-// MODE 0: linear gather (forward, unit-stride dgrad).  MODE 1: divide gather (strided dgrad).
-// FAST: taps <= 62 and MODE 0 -> tap-mask path.
+// 256 threads = 4 waves side by side along N: every wave owns all BM = 32*TM rows of the block tile and
+// BN/4 of its columns (TN = BN/128 MFMA tiles wide).  LDS tiles are stored [row][k] with an 80-byte row
+// pitch, so a lane fetches FOUR k-steps of its operand row with one conflict-free ds_read_b128 and a
+// k-tile of 16 is 2 reads per operand tile followed by an uninterrupted chain of 8*TM*TN MFMAs.  (A lane of
+// half h holds k = 8t + 4h + e of its row; MFMA step (t, e) therefore sums k = 8t+e and 8t+4+e -- the same
+// permutation on both operands.)
+// FAST: tap-mask path (class has <= 62 taps).  VEC: float4 gathers (BN = 256, every lane owns 4
+// consecutive columns, a wave covers one whole tile row per load).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int WM, int WN, int MODE, bool FAST>
+constexpr int LDK = BK + 4;     // LDS row pitch in floats (80 B)
+
+template <int TM, int BN, bool FAST, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, float* __restrict__ slab, IgemmParams p) {
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int A_F4 = BK * BM / 4 / 256;     // float4 loads per thread for the A tile
-  constexpr int B_PER = BK * BN / 256;        // gathers per thread for the B tile (8)
-  static_assert(A_F4 >= 1, "tile too small");
-  static_assert(!(FAST && MODE == 1), "fast path is linear-gather only");
+  constexpr int BM = 32 * TM, TN = BN / 128, WN = 4;
+  constexpr int A_F4 = (BM * 4 + 255) / 256;               // float4 loads per thread for the A tile (BM x 16)
+  constexpr int B_PER = VEC ? 4 : 8;                       // gathers per thread for the B tile
+  static_assert(!VEC || (BN == 256 && FAST), "VEC variant: 256 columns, tap-mask path");
+  static_assert(BN == 128 || BN == 256, "BN");
 
-  __shared__ float As[2][BK][BM];
-  __shared__ float Bs[2][BK][BN];
+  __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
+  __shared__ int taptab[64];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   int bid = gca_xcd_remap(blockIdx.x, gridDim.x);
   const int split = bid % p.splits; bid /= p.splits;
   const int tileM = bid % p.tilesM, tileN = bid / p.tilesM;
 
+  if (FAST) {
+    if (tid < 64) taptab[tid] = reinterpret_cast<const int*>(table + p.Kpad)[tid];
+    __syncthreads();
+  }
+
   // ---- per-thread column (GEMM-N) state: fixed for the whole K loop
-  const int col = tid % BN;
-  const int r0 = (tid / BN) * B_PER;          // this thread's first B row inside a k-tile (wave-uniform)
+  const int col = VEC ? 4 * lane : tid % BN;
+  const int r0 = VEC ? wn * B_PER : (tid / BN) * B_PER;    // first B k-row of this thread inside a k-tile (wave-uniform)
   const long long ng = (long long)tileN * BN + col;
   const bool cvalid = ng < p.Ntot;
-  const int OSP = p.OD * p.OH * p.OW, OHW = p.OH * p.OW;
+  const int QSP = p.QD * p.QH * p.QW, QHW = p.QH * p.QW;
   const int SHW = p.SH * p.SW;
-  int id0 = 0, ih0 = 0, iw0 = 0;
-  int colbase = 0;                            // 32-bit element index (tensors are < 2^30 elements)
+  int id0, ih0, iw0, colbase;                              // 32-bit element index (tensors are < 2^30 elements)
   {
     const long long ngc = cvalid ? ng : 0;
-    const int img = (int)(ngc / OSP);
-    const int sp = (int)(ngc - (long long)img * OSP);
-    const int od = sp / OHW, r = sp - od * OHW;
-    const int oh = r / p.OW, ow = r - oh * p.OW;
-    if (MODE == 0) {
-      id0 = od * p.m_d + p.o_d; ih0 = oh * p.m_h + p.o_h; iw0 = ow * p.m_w + p.o_w;
-      colbase = (int)((long long)img * p.src_nstride) + id0 * SHW + ih0 * p.SW + iw0;
-    } else {
-      id0 = od + p.o_d; ih0 = oh + p.o_h; iw0 = ow + p.o_w;
-      colbase = (int)((long long)img * p.src_nstride);
-    }
+    const int img = (int)(ngc / QSP);
+    const int sp = (int)(ngc - (long long)img * QSP);
+    const int qd = sp / QHW, r = sp - qd * QHW;
+    const int qh = r / p.QW, qw = r - qh * p.QW;
+    id0 = qd * p.m_d + p.o_d; ih0 = qh * p.m_h + p.o_h; iw0 = qw * p.m_w + p.o_w;
+    colbase = (int)((long long)img * p.src_nstride) + id0 * SHW + ih0 * p.SW + iw0;
   }
   const bool chkD = p.chk & 1, chkH = p.chk & 2, chkW = p.chk & 4;
 
-  // tap-validity mask: bit t = tap t of this column's window lies inside the source tensor
-  unsigned mlo = 0, mhi = 0;
+  // Gathers go through a buffer resource: an out-of-range offset returns 0 in hardware, so an invalid
+  // window element costs nothing but an OR of all-ones into its 32-bit byte offset -- no post-load select.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, p.src_bytes, 0x00020000);
+  const unsigned cb4 = (unsigned)colbase * 4u;
+
+  // tap-INvalidity mask: bit t = 1 -> tap t of this column's window falls outside the source tensor
+  // (bits of taps the class does not have, and tap id 63 = padded table row, stay 1)
+  unsigned ilo = 0xffffffffu, ihi = 0xffffffffu;
   if (FAST) {
-    int a = 0, b = 0, c = 0;
-    const int ntaps = p.kd * p.kh * p.kw;
-    for (int t = 0; t < ntaps; ++t) {
+    for (int t = 0; t < p.ntaps; ++t) {
+      const int pk = taptab[t];
+      const int dd = (pk << 24) >> 24, dh = (pk << 16) >> 24, dw = (pk << 8) >> 24;
       bool ok = cvalid;
-      if (chkD) ok = ok & ((unsigned)(id0 + p.tap_sign * a) < (unsigned)p.SD);
-      if (chkH) ok = ok & ((unsigned)(ih0 + p.tap_sign * b) < (unsigned)p.SH);
-      if (chkW) ok = ok & ((unsigned)(iw0 + p.tap_sign * c) < (unsigned)p.SW);
-      if (t < 32) mlo |= (unsigned)ok << t; else mhi |= (unsigned)ok << (t - 32);
-      if (++c == p.kw) { c = 0; if (++b == p.kh) { b = 0; ++a; } }
+      if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.SD);
+      if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
+      if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
+      if (t < 32) ilo &= ~((unsigned)ok << t); else ihi &= ~((unsigned)ok << (t - 32));
     }
   }
 
-  float breg[B_PER];
+  float breg[VEC ? 1 : B_PER];
+  float4 bvec[VEC ? B_PER : 1];
   float4 areg[A_F4];
-  unsigned bmask = 0;
+  const float* arow = apack + (long long)tileM * BM * p.Kpad;      // packed weights [Mpad][Kpad], k contiguous
 
   auto load_tiles = [&](int kt) {
-    // A: packed weights [Kpad][Mpad], rows kt*BK.., cols tileM*BM..
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-      areg[i] = *reinterpret_cast<const float4*>(apack + (long long)(kt * BK + row) * p.Mpad + tileM * BM + c4 * 4);
+      if ((BM * 4) % 256 == 0 || idx < BM * 4)
+        areg[i] = *reinterpret_cast<const float4*>(arow + (long long)(idx >> 2) * p.Kpad + kt * BK + (idx & 3) * 4);
     }
     // B: gathered window.  Rows are uniform across the wave: fetch their table entries first (scalar,
     // one batch), then issue all gathers back to back.
@@ -142,54 +150,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     int2 e[B_PER];
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) e[i] = trow[i];
-    bmask = 0;      // validity bits; applied when the tile is written to LDS, so the loads stay in flight
-    if (FAST) {
-      int idx[B_PER];
+    unsigned voff[B_PER];
 #pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
-        const int tap6 = (e[i].y >> 25) & 63;            // 63 = padded row, never valid
-        const unsigned m = tap6 < 32 ? mlo : mhi;
-        const unsigned ok = (m >> (tap6 & 31)) & 1u;
-        bmask |= ok << i;
-        idx[i] = ok ? colbase + e[i].x : 0;
-      }
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) breg[i] = src[(unsigned)idx[i]];
-    } else {
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
+    for (int i = 0; i < B_PER; ++i) {
+      int inv;                                            // 0 = valid, -1 = invalid
+      if (FAST) {
+        const int tap6 = (e[i].y >> 25) & 63;
+        const unsigned m = tap6 < 32 ? ilo : ihi;
+        inv = (int)(m << (31 - (tap6 & 31))) >> 31;
+      } else {
         int off, dd, dh, dw, rvalid;
         decode_row(e[i], off, dd, dh, dw, rvalid);
-        bool ok = cvalid & (rvalid != 0);
-        int idx;
-        if (MODE == 0) {
-          if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.SD);
-          if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
-          if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
-          idx = colbase + off;
-        } else {
-          const unsigned td = (unsigned)(id0 + dd), th = (unsigned)(ih0 + dh), tw = (unsigned)(iw0 + dw);
-          unsigned qd, qh, qw;
-          if (p.m_d == 1) qd = td; else if (p.m_d == 2) { qd = td >> 1; ok = ok & !(td & 1); } else { qd = td / (unsigned)p.m_d; ok = ok & (qd * p.m_d == td); }
-          if (p.m_h == 1) qh = th; else if (p.m_h == 2) { qh = th >> 1; ok = ok & !(th & 1); } else { qh = th / (unsigned)p.m_h; ok = ok & (qh * p.m_h == th); }
-          if (p.m_w == 1) qw = tw; else if (p.m_w == 2) { qw = tw >> 1; ok = ok & !(tw & 1); } else { qw = tw / (unsigned)p.m_w; ok = ok & (qw * p.m_w == tw); }
-          ok = ok & (qd < (unsigned)p.SD) & (qh < (unsigned)p.SH) & (qw < (unsigned)p.SW);
-          idx = colbase + off + (int)qd * SHW + (int)qh * p.SW + (int)qw;
-        }
-        bmask |= (unsigned)ok << i;
-        breg[i] = src[(unsigned)(ok ? idx : 0)];
+        bool k = cvalid & (rvalid != 0);
+        if (chkD) k = k & ((unsigned)(id0 + dd) < (unsigned)p.SD);
+        if (chkH) k = k & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
+        if (chkW) k = k & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
+        inv = k ? 0 : -1;
       }
+      voff[i] = (cb4 + (unsigned)e[i].x) | (unsigned)inv;      // table offsets are in bytes
+    }
+    if (VEC) {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, v[i]) on the elements makes hipcc
+        // (ROCm 7.2) narrow the load to one dword and replicate it.
+        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[i], 0, 0));
+        bvec[i] = make_float4(f.x, f.y, f.z, f.w);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) breg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[i], 0, 0));
     }
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
       const int idx = tid + i * 256;
-      const int row = idx / (BM / 4), c4 = idx % (BM / 4);
-      *reinterpret_cast<float4*>(&As[buf][row][c4 * 4]) = areg[i];
+      if ((BM * 4) % 256 == 0 || idx < BM * 4)
+        *reinterpret_cast<float4*>(&As[buf][idx >> 2][(idx & 3) * 4]) = areg[i];
     }
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) Bs[buf][r0 + i][col] = ((bmask >> i) & 1u) ? breg[i] : 0.f;
+    if (VEC) {      // 4 k-rows x 4 columns per thread: transpose in registers, one b128 per column
+      *reinterpret_cast<float4*>(&Bs[buf][col + 0][r0]) = make_float4(bvec[0].x, bvec[1].x, bvec[2].x, bvec[3].x);
+      *reinterpret_cast<float4*>(&Bs[buf][col + 1][r0]) = make_float4(bvec[0].y, bvec[1].y, bvec[2].y, bvec[3].y);
+      *reinterpret_cast<float4*>(&Bs[buf][col + 2][r0]) = make_float4(bvec[0].z, bvec[1].z, bvec[2].z, bvec[3].z);
+      *reinterpret_cast<float4*>(&Bs[buf][col + 3][r0]) = make_float4(bvec[0].w, bvec[1].w, bvec[2].w, bvec[3].w);
+    } else {        // 8 consecutive k-rows of one column
+      *reinterpret_cast<float4*>(&Bs[buf][col][r0]) = make_float4(breg[0], breg[1], breg[2], breg[3]);
+      *reinterpret_cast<float4*>(&Bs[buf][col][r0 + 4]) = make_float4(breg[4], breg[5], breg[6], breg[7]);
+    }
   };
 
   f32x16 acc[TM][TN];
@@ -213,24 +221,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const int buf = (kt - kt0) & 1;
     if (kt + 1 < kt1) load_tiles(kt + 1);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float a[TM], b[TN];
+    for (int t = 0; t < 2; ++t) {
+      float4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk + lh][wm * (TM * 32) + i * 32 + ll];
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][i * 32 + ll][8 * t + 4 * lh]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk + lh][wn * (TN * 32) + j * 32 + ll];
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][8 * t + 4 * lh]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
     }
     if (kt + 1 < kt1) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int mbase = tileM * BM + wm * (TM * 32);
+  const int mbase = tileM * BM;
   if (p.splits > 1) {
     // partial tile -> slab[split][m][n]; bias / accumulate / BN sums happen in conv_splitk_finish_kernel
     float* sl = slab + (long long)split * p.DK * p.Ntot;
@@ -249,14 +261,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     }
     return;
   }
+  const int DHW = p.DH * p.DW;
+  const long long DSP = (long long)p.DD * DHW;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long long n = (long long)tileN * BN + wn * (TN * 32) + j * 32 + ll;
     const bool nv = n < p.Ntot;
     const long long nc = nv ? n : 0;
-    const int img = (int)(nc / OSP);
-    const int sp = (int)(nc - (long long)img * OSP);
-    float* d0 = dst + ((long long)img * p.DK) * OSP + sp;
+    const int img = (int)(nc / QSP);
+    const int sp = (int)(nc - (long long)img * QSP);
+    const int qd = sp / QHW, rr = sp - qd * QHW;
+    const int qh = rr / p.QW, qw = rr - qh * p.QW;
+    const long long dsp = (long long)(qd * p.dm_d + p.do_d) * DHW + (qh * p.dm_h + p.do_h) * p.DW + (qw * p.dm_w + p.do_w);
+    float* d0 = dst + ((long long)img * p.DK) * DSP + dsp;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float old[16];
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          old[r] = (nv && m < p.DK) ? d0[(long long)m * OSP] : 0.f;
+          old[r] = (nv && m < p.DK) ? d0[(long long)m * DSP] : 0.f;
         }
       }
 #pragma unroll
@@ -274,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
           float v = acc[i][j][r];
           if (bias) v += bias[m];
           if (p.accumulate) v += old[r];
-          d0[(long long)m * OSP] = v;
+          d0[(long long)m * DSP] = v;
         }
       }
     }
@@ -302,25 +319,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 }
 
 // Split-K finishing pass, grid (channels, parts): sum the slabs in fixed order, add bias, (+=) store in
-// NCDHW, and emit the BN partial sums [K][parts] of the conv output.
+// NCDHW (through the class's destination map), and emit the BN partial sums [K][parts].
 constexpr int FINISH_CHUNK = 4096;
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
     const float* __restrict__ slab, int splits, const float* __restrict__ bias, float* __restrict__ dst,
-    float* __restrict__ psum, float* __restrict__ psq, int DK, int OSP, long long Ntot, int accumulate) {
+    float* __restrict__ psum, float* __restrict__ psq, IgemmParams p) {
   __shared__ double sh[4];
   const int m = blockIdx.x, part = blockIdx.y, P = gridDim.y;
   const float b = bias ? bias[m] : 0.f;
   const long long lo = (long long)part * FINISH_CHUNK;
-  long long hi = lo + FINISH_CHUNK; if (hi > Ntot) hi = Ntot;
+  long long hi = lo + FINISH_CHUNK; if (hi > p.Ntot) hi = p.Ntot;
+  const int QSP = p.QD * p.QH * p.QW, QHW = p.QH * p.QW, DHW = p.DH * p.DW;
+  const long long DSP = (long long)p.DD * DHW;
   double s = 0.0, q = 0.0;
   for (long long n = lo + threadIdx.x; n < hi; n += 256) {
     float v = 0.f;
-    for (int k = 0; k < splits; ++k) v += slab[((long long)k * DK + m) * Ntot + n];
+    for (int k = 0; k < splits; ++k) v += slab[((long long)k * p.DK + m) * p.Ntot + n];
     s += (double)v; q += (double)v * (double)v;       // statistics of the conv output proper (no bias on that path)
     v += b;
-    const long long img = n / OSP, sp = n - img * OSP;
-    float* d = dst + (img * DK + m) * OSP + sp;
-    if (accumulate) v += *d;
+    const int img = (int)(n / QSP);
+    const int sp = (int)(n - (long long)img * QSP);
+    const int qd = sp / QHW, rr = sp - qd * QHW;
+    const int qh = rr / p.QW, qw = rr - qh * p.QW;
+    const long long dsp = (long long)(qd * p.dm_d + p.do_d) * DHW + (qh * p.dm_h + p.do_h) * p.DW + (qw * p.dm_w + p.do_w);
+    float* d = dst + ((long long)img * p.DK + m) * DSP + dsp;
+    if (p.accumulate) v += *d;
     *d = v;
   }
   if (psum) {
@@ -330,503 +353,429 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// wgrad: both operands are gathered with lanes along the (contiguous) spatial axis.
-//   A[k'][m] = dY[img, m, o]       B[k'][n'] = X[img, c(n'), o*s - p + tap(n')]
-// One workgroup = one (tileM, tileN, split) and writes its partial tile to a slab.
-// ---------------------------------------------------------------------------------------------
-struct WgradParams {
-  int NB, C, D, H, W, K, OD, OH, OW;
-  int sd, sh, sw, pd, ph, pw;
-  int Kred;                 // C*taps  (GEMM N)
-  int tilesM, tilesN, splits;
-  int kt_per_split, kt_total;
-  int chk;
-  long long Ktot;           // NB*OD*OH*OW (GEMM K)
-  long long x_nstride;
+// packed[m][k] (k contiguous, zero padded to [Mrows][Kpad]), k = (ch, t') over the class's tap grid:
+// tap = ((kd0+sd*a)*KH + (kh0+sh*b))*KW + (kw0+sw*c).  fwd (which 0): value = W[m][ch][tap];
+// dgrad (which 1): value = W[ch][m][tap].  One thread per packed element, k fastest (coalesced writes; the
+// reads are contiguous for the forward layout and tap-strided for dgrad -- weights are L2-resident).
+struct PackParams {
+  int Kred, M, Kpad, Mrows;
+  int ntaps, nb, nc;           // class tap grid: ntaps = na*nb*nc
+  int k0d, k0h, k0w, sd, sh, sw;
+  int KH, KW, T;               // full kernel
+  long long s_ch, s_m;         // element strides of `ch` and `m` in W
+};
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, PackParams p) {
+  const long long total = (long long)p.Mrows * p.Kpad;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / p.Kpad), k = (int)(i - (long long)m * p.Kpad);
+    float v = 0.f;
+    if (m < p.M && k < p.Kred) {
+      const int ch = k / p.ntaps, tl = k - ch * p.ntaps;
+      const int a = tl / (p.nb * p.nc), r = tl - a * (p.nb * p.nc), b = r / p.nc, c = r - b * p.nc;
+      const int tap = ((p.k0d + p.sd * a) * p.KH + (p.k0h + p.sh * b)) * p.KW + (p.k0w + p.sw * c);
+      v = w[(long long)ch * p.s_ch + tap + (long long)m * p.s_m];
+    }
+    packed[i] = v;
+  }
+}
+
+__global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// ---- host side: problem classes ---------------------------------------------------------------
+struct ClassInfo {
+  int na, nb, nc, ntaps;        // tap grid of the class
+  int k0[3], ks[3];             // tap = k0 + ks*j per dim
+  int dl0[3], dls[3];           // gather delta of tap index j per dim: dl0 + dls*j
+  int q[3];                     // iteration sub-grid
+  int dm[3], dof[3];            // destination = q*dm + dof
+  int m[3], o[3];               // source = q*m + o + delta
+  int srcC, M;                  // gathered channels, GEMM M
+  long long Kred, Kpad;
+  long long table_off;          // int2 units inside the table buffer
+  long long pack_off;           // floats inside the packed buffer
+  bool vec;
 };
 
-template <int BM, int BNW>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, const int2* __restrict__ table,
-    float* __restrict__ slab, WgradParams p) {
-  constexpr int WM = 2, WN = 2;
-  constexpr int TM = BM / WM / 32, TN = BNW / WN / 32;
-  constexpr int LDA = BM + 1, LDB = BNW + 1;     // odd strides: lanes run along k' on the LDS write
-  constexpr int A_PER = BM / 8, B_PER = BNW / 8;
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int pack_rows(int M);
 
-  __shared__ float As[WBK * LDA];
-  __shared__ float Bs[WBK * LDB];
-  __shared__ int2 Ts[BNW];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  int bid = blockIdx.x;
-  const int split = bid % p.splits; bid /= p.splits;
-  const int tileM = bid % p.tilesM, tileN = bid / p.tilesM;
-
-  if (tid < BNW) Ts[tid] = table[tileN * BNW + tid];
-  __syncthreads();
-
-  const int kl = tid & 31, g = tid >> 5;
-  const int OSP = p.OD * p.OH * p.OW, OHW = p.OH * p.OW;
-  const int HW = p.H * p.W;
-  const bool chkD = p.chk & 1, chkH = p.chk & 2, chkW = p.chk & 4;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int kt0 = split * p.kt_per_split;
-  int kt1 = kt0 + p.kt_per_split; if (kt1 > p.kt_total) kt1 = p.kt_total;
-  const int lh = lane >> 5, ll = lane & 31;
-
-  float areg[A_PER], breg[B_PER];
-  unsigned amask = 0, bmask = 0;     // validity bits, applied at the LDS store so the loads stay in flight
-  auto load_tiles = [&](int kt) {
-    const long long kp = (long long)kt * WBK + kl;
-    const bool kv = kp < p.Ktot;
-    const long long kc = kv ? kp : 0;
-    const int img = (int)(kc / OSP);
-    const int o = (int)(kc - (long long)img * OSP);
-    const int od = o / OHW, r = o - od * OHW;
-    const int oh = r / p.OW, ow = r - oh * p.OW;
-    // A: dY[img, m, o]  (32-bit element indices; tensors are < 2^30 elements)
-    const int abase = img * p.K * OSP + o;
-    int aidx[A_PER];
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) {
-      const int m = tileM * BM + g + 8 * i;
-      aidx[i] = (kv & (m < p.K)) ? abase + m * OSP : -1;
-    }
-    amask = 0;
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) { amask |= (unsigned)(aidx[i] >= 0) << i; areg[i] = dy[(unsigned)(aidx[i] < 0 ? 0 : aidx[i])]; }
-    // B: X window element for (c, tap) = table row n'
-    const int id0 = od * p.sd - p.pd, ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-    const int bbase = (int)((long long)img * p.x_nstride) + id0 * HW + ih0 * p.W + iw0;
-    int bidx[B_PER];
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-      const int2 e = Ts[g + 8 * j];
-      int off, dd, dh, dw, rvalid;
-      decode_row(e, off, dd, dh, dw, rvalid);
-      bool ok = kv & (rvalid != 0);
-      if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.D);
-      if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.H);
-      if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.W);
-      bidx[j] = ok ? bbase + off : -1;
-    }
-    bmask = 0;
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) { bmask |= (unsigned)(bidx[j] >= 0) << j; breg[j] = x[(unsigned)(bidx[j] < 0 ? 0 : bidx[j])]; }
+// which: 0 forward, 1 dgrad
+void build_classes(const gca_conv_geom* g, int which, std::vector<ClassInfo>& out) {
+  const int kdim[3] = {g->kd, g->kh, g->kw}, sdim[3] = {g->sd, g->sh, g->sw}, pdim[3] = {g->pd, g->ph, g->pw};
+  const int in[3] = {g->D, g->H, g->W}, od[3] = {g->OD, g->OH, g->OW};
+  long long toff = 0, poff = 0;
+  auto finish = [&](ClassInfo& c) {
+    c.ntaps = c.na * c.nb * c.nc;
+    c.Kred = (long long)c.srcC * c.ntaps;
+    c.Kpad = gca_round_up(c.Kred, BK);
+    c.table_off = toff; c.pack_off = poff;
+    toff += c.Kpad + 32;                                   // rows + 64-int tap-delta table
+    poff += c.Kpad * pack_rows(c.M);
+    // VEC: rows are contiguous runs of the image -> no taps / stride / padding in H and W, float4-aligned planes
+    const int SH = which == 0 ? in[1] : od[1], SW = which == 0 ? in[2] : od[2];
+    c.vec = c.nb == 1 && c.nc == 1 && c.m[1] == 1 && c.m[2] == 1 && c.o[1] + c.dl0[1] == 0 && c.o[2] + c.dl0[2] == 0 &&
+            c.dm[1] == 1 && c.dm[2] == 1 && c.dof[1] == 0 && c.dof[2] == 0 && c.q[1] == SH && c.q[2] == SW &&
+            (SH * SW) % 4 == 0 && c.ntaps <= FAST_MAX_TAPS &&
+            (which == 1 || g->x_batch_stride % 4 == 0);
+    out.push_back(c);
   };
-  auto store_tiles = [&]() {
-#pragma unroll
-    for (int i = 0; i < A_PER; ++i) As[kl * LDA + g + 8 * i] = ((amask >> i) & 1u) ? areg[i] : 0.f;
-#pragma unroll
-    for (int j = 0; j < B_PER; ++j) Bs[kl * LDB + g + 8 * j] = ((bmask >> j) & 1u) ? breg[j] : 0.f;
-  };
-
-  if (kt0 < kt1) load_tiles(kt0);
-  for (int kt = kt0; kt < kt1; ++kt) {
-    __syncthreads();                 // previous tile fully consumed
-    store_tiles();
-    __syncthreads();
-    if (kt + 1 < kt1) load_tiles(kt + 1);   // overlaps the MFMA phase below
-#pragma unroll
-    for (int kk = 0; kk < WBK; kk += 2) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[(kk + lh) * LDA + wm * (TM * 32) + i * 32 + ll];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[(kk + lh) * LDB + wn * (TN * 32) + j * 32 + ll];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  if (which == 0) {
+    ClassInfo c{};
+    c.na = g->kd; c.nb = g->kh; c.nc = g->kw;
+    for (int d = 0; d < 3; ++d) {
+      c.k0[d] = 0; c.ks[d] = 1; c.dl0[d] = 0; c.dls[d] = 1;
+      c.q[d] = od[d]; c.dm[d] = 1; c.dof[d] = 0; c.m[d] = sdim[d]; c.o[d] = -pdim[d];
     }
+    c.srcC = g->C; c.M = g->K;
+    finish(c);
+    return;
   }
-
-  float* out = slab + (long long)split * p.K * p.Kred;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = tileN * BNW + wn * (TN * 32) + j * 32 + ll;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = tileM * BM + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.K && n < p.Kred) out[(long long)m * p.Kred + n] = acc[i][j][r];
+  // dgrad: one class per residue (rho_d, rho_h, rho_w) of the destination position modulo the stride
+  for (int rd = 0; rd < sdim[0]; ++rd)
+    for (int rh = 0; rh < sdim[1]; ++rh)
+      for (int rw = 0; rw < sdim[2]; ++rw) {
+        const int rho[3] = {rd, rh, rw};
+        ClassInfo c{};
+        int cnt[3];
+        bool empty = false;
+        for (int d = 0; d < 3; ++d) {
+          const int k0 = (rho[d] + pdim[d]) % sdim[d];
+          cnt[d] = k0 < kdim[d] ? (kdim[d] - 1 - k0) / sdim[d] + 1 : 0;
+          c.k0[d] = k0; c.ks[d] = sdim[d];
+          c.dl0[d] = (rho[d] + pdim[d] - k0) / sdim[d];    // exact
+          c.dls[d] = -1;                                    // next tap of the class is one source step back
+          c.q[d] = rho[d] < in[d] ? (in[d] - rho[d] + sdim[d] - 1) / sdim[d] : 0;
+          c.dm[d] = sdim[d]; c.dof[d] = rho[d];
+          c.m[d] = 1; c.o[d] = 0;
+          if (cnt[d] == 0 || c.q[d] == 0) empty = true;
+        }
+        c.na = cnt[0]; c.nb = cnt[1]; c.nc = cnt[2];
+        c.srcC = g->K; c.M = g->C;
+        if (empty) { c.na = c.nb = c.nc = 0; c.ntaps = 0; c.Kred = c.Kpad = 0; c.table_off = toff; c.pack_off = poff; c.vec = false; out.push_back(c); continue; }
+        finish(c);
       }
+}
+
+inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, IgemmParams& p) {
+  if (which == 0) { p.SC = g->C; p.SD = g->D; p.SH = g->H; p.SW = g->W; p.DD = g->OD; p.DH = g->OH; p.DW = g->OW; }
+  else { p.SC = g->K; p.SD = g->OD; p.SH = g->OH; p.SW = g->OW; p.DD = g->D; p.DH = g->H; p.DW = g->W; }
+  p.DK = c.M;
+  p.QD = c.q[0]; p.QH = c.q[1]; p.QW = c.q[2];
+  p.dm_d = c.dm[0]; p.dm_h = c.dm[1]; p.dm_w = c.dm[2];
+  p.do_d = c.dof[0]; p.do_h = c.dof[1]; p.do_w = c.dof[2];
+  p.m_d = c.m[0]; p.m_h = c.m[1]; p.m_w = c.m[2];
+  p.o_d = c.o[0]; p.o_h = c.o[1]; p.o_w = c.o[2];
+  p.ntaps = c.ntaps;
+  p.Kpad = (int)c.Kpad; p.Mpad = (int)gca_round_up(c.M, MPAD);
+  p.Ntot = (long long)g->N * c.q[0] * c.q[1] * c.q[2];
+  p.src_nstride = which == 0 ? (g->x_batch_stride ? g->x_batch_stride : (long long)g->C * g->D * g->H * g->W)
+                             : (long long)g->K * g->OD * g->OH * g->OW;
+  {
+    const long long span = (long long)g->N * p.src_nstride * 4;
+    p.src_bytes = span > 0xfffff000LL ? 0xfffff000u : (unsigned)span;
   }
-}
-
-// dw[i] (+)= sum_s slab[s][i]   (fixed order: deterministic)
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
-                                     int splits, int accumulate) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[(long long)k * n + i];
-  if (accumulate) s += dw[i];
-  dw[i] = s;
-}
-
-// packed[k][m] = W[(k / T) * s_kq + (k % T) + m * s_m]  (zero outside k<Kred, m<M), 32x32 LDS transpose
-__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, int Kred, int M,
-                                 int Kpad, int Mpad, int T, long long s_kq, long long s_m) {
-  __shared__ float tile[32][33];
-  const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty 0..7
-  for (int r = ty; r < 32; r += 8) {
-    const int m = m0 + r, k = k0 + tx;
-    float v = 0.f;
-    if (m < M && k < Kred) v = w[(long long)(k / T) * s_kq + (k % T) + (long long)m * s_m];
-    tile[r][tx] = v;
+  // bounds tests: skip a dimension when every tap of every column stays inside by construction
+  const int lim[3] = {p.SD, p.SH, p.SW};
+  int chk = 0;
+  const int cn[3] = {c.na, c.nb, c.nc};
+  for (int d = 0; d < 3; ++d) {
+    const int dmin = c.dls[d] > 0 ? c.dl0[d] : c.dl0[d] + c.dls[d] * (cn[d] - 1);
+    const int dmax = c.dls[d] > 0 ? c.dl0[d] + c.dls[d] * (cn[d] - 1) : c.dl0[d];
+    const int lo = c.o[d] + dmin, hi = (c.q[d] - 1) * c.m[d] + c.o[d] + dmax;
+    if (lo < 0 || hi >= lim[d]) chk |= 1 << d;
   }
-  __syncthreads();
-  for (int r = ty; r < 32; r += 8) {
-    const int k = k0 + r, m = m0 + tx;
-    if (k < Kpad && m < Mpad) packed[(long long)k * Mpad + m] = tile[tx][r];
-  }
+  p.chk = chk;
+  if (const char* e = getenv("GCA_DEBUG_CHK")) p.chk |= atoi(e);   // experiments only
 }
-
-__global__ void bias_grad_kernel(const float* __restrict__ dy, long long N, long long K, long long SP,
-                                 float* __restrict__ db, int accumulate) {
-  __shared__ float sh[4];
-  const long long k = blockIdx.x;
-  float s = 0.f;
-  const long long tot = N * SP;
-  for (long long i = threadIdx.x; i < tot; i += blockDim.x) {
-    const long long n = i / SP, sp = i - n * SP;
-    s += dy[(n * K + k) * SP + sp];
-  }
-  s = gca_block_sum256(s, sh);
-  if (threadIdx.x == 0) db[k] = accumulate ? db[k] + s : s;
-}
-
-inline bool geom_ok(const gca_conv_geom* g) {
-  if (!g) return false;
-  if (g->N <= 0 || g->C <= 0 || g->D <= 0 || g->H <= 0 || g->W <= 0 || g->K <= 0) return false;
-  if (g->kd <= 0 || g->kh <= 0 || g->kw <= 0 || g->sd <= 0 || g->sh <= 0 || g->sw <= 0) return false;
-  if (g->pd < 0 || g->ph < 0 || g->pw < 0) return false;
-  if (g->kd > 127 || g->kh > 127 || g->kw > 127) return false;
-  const int od = (g->D + 2 * g->pd - g->kd) / g->sd + 1;
-  const int oh = (g->H + 2 * g->ph - g->kh) / g->sh + 1;
-  const int ow = (g->W + 2 * g->pw - g->kw) / g->sw + 1;
-  if (od != g->OD || oh != g->OH || ow != g->OW || od <= 0 || oh <= 0 || ow <= 0) return false;
-  // the kernels address both tensors with 32-bit byte offsets from their base: < 2^30 elements (4 GiB) each
-  const long long cdhw = (long long)g->C * g->D * g->H * g->W;
-  if (g->x_batch_stride != 0 && g->x_batch_stride < cdhw) return false;
-  const long long in_elems = (long long)g->N * (g->x_batch_stride ? g->x_batch_stride : cdhw);
-  const long long out_elems = (long long)g->N * g->K * od * oh * ow;
-  if (in_elems >= (1LL << 30) || out_elems >= (1LL << 30)) return false;
-  for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && v != 64 && v != 128) return false;
-  for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
-  return true;
-}
-
-inline int taps(const gca_conv_geom* g) { return g->kd * g->kh * g->kw; }
-inline bool unit_stride(const gca_conv_geom* g) { return g->sd == 1 && g->sh == 1 && g->sw == 1; }
 
 // ---- launch configuration ------------------------------------------------------------------
-struct IgemmCfg { int bm; int splits; int kt_per_split; };
+struct IgemmCfg { int bm; int bn; int splits; int kt_per_split; };
+
+inline int pack_rows(int M) { return (int)gca_round_up(M, 32) + 128; }   // every tile height up to 160 stays in bounds
 
 // Heuristic default (the host side may override it per geometry after measuring: gca_conv_geom.tune_*).
-// BM = 128 halves the gather work per FLOP (a gathered B element feeds 128 output channels instead of 64)
-// but only two such workgroups fit a CU; the K loop is split when the tile grid cannot occupy the CUs and
-// the partial slabs stay small.
-inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, int force_bm, int force_splits) {
-  const long long tn = gca_ceil_div(Ntot, BN);
-  IgemmCfg best{64, 1, nk};
+// Tile = 32*TM rows (TM = 1..5, picked to minimise padded rows) x 128 columns, or x 256 columns with float4
+// gathers for pointwise-in-space classes; the K loop is split when the tile grid cannot occupy the CUs and
+// the partial slabs stay small.  tune code: rows | 1024 for the 256-column variant.
+inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force_bm, int force_splits) {
+  IgemmCfg best{64, 128, 1, nk};
   double best_cost = 1e300;
-  for (int bm = 64; bm <= 128; bm += 64) {
-    if (force_bm ? bm != force_bm : (bm == 128 && M <= 64)) continue;
-    const long long tiles = gca_ceil_div(M, bm) * tn;
-    int s = 1;
-    if (force_splits > 0) s = force_splits;
-    else if (tiles < 2 * NUM_CU && nk >= 8 && (long long)M * Ntot <= (1LL << 20)) {
-      long long want = gca_ceil_div(2 * NUM_CU, tiles);
-      if (want > nk / 4) want = nk / 4;
-      if (want > 16) want = 16;
-      if (want > 1) s = (int)want;
+  const bool force_vec = force_bm >= 1024;
+  const int force_rows = force_bm & 1023;
+  for (int v = 0; v < 2; ++v) {
+    if (v == 1 && !vec_ok) continue;
+    if (force_bm && (v == 1) != (force_vec && vec_ok)) continue;
+    for (int tm = 1; tm <= 5; ++tm) {
+      const int bm = 32 * tm, bn = v ? 256 : 128;
+      if (force_rows && bm != force_rows) continue;
+      const long long tiles = gca_ceil_div(M, bm) * gca_ceil_div(Ntot, bn);
+      int s = 1;
+      if (force_splits > 0) s = force_splits;
+      else if (tiles < 2 * NUM_CU && nk >= 8 && (long long)M * Ntot <= (1LL << 20)) {
+        long long want = gca_ceil_div(2 * NUM_CU, tiles);
+        if (want > nk / 4) want = nk / 4;
+        if (want > 16) want = 16;
+        if (want > 1) s = (int)want;
+      }
+      if (s > nk) s = nk;
+      if (s < 1) s = 1;
+      const int per = (int)gca_ceil_div(nk, s);
+      s = (int)gca_ceil_div(nk, per);
+      const double wg_per_cu = (double)(tiles * s) / NUM_CU;
+      const double occ = wg_per_cu < 1.0 ? 0.55 : (wg_per_cu < 2.0 ? 0.75 : 1.0);   // latency hiding needs >= 2 WGs / CU
+      const double rounds = (double)gca_ceil_div(tiles * s, NUM_CU);
+      // taller tiles amortise the gather over more MFMAs; the float4 variant gathers 4x cheaper
+      const double eff = (0.55 + 0.1 * tm) * (v ? 1.15 : 1.0) * occ;
+      const double work = (double)bm * bn * per;
+      const double cost = rounds * work / eff + (s > 1 ? 0.05 * rounds * work + 8.0 * bm * bn : 0.0);
+      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per}; }
     }
-    if (s > nk) s = nk;
-    if (s < 1) s = 1;
-    const int per = (int)gca_ceil_div(nk, s);
-    s = (int)gca_ceil_div(nk, per);
-    const double wg_per_cu = (double)(tiles * s) / NUM_CU;
-    const double occ = wg_per_cu < 1.0 ? 0.55 : (wg_per_cu < 2.0 ? 0.75 : 1.0);   // latency hiding needs >= 2 WGs / CU
-    const double rounds = (double)gca_ceil_div(tiles * s, NUM_CU);
-    const double eff = (bm == 128 ? 1.0 : 0.85) * occ;
-    const double cost = rounds * bm * (double)per / eff + (s > 1 ? 0.05 * rounds * bm * per + 8.0 * bm : 0.0);
-    if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, s, per}; }
   }
   return best;
 }
 
-template <int BM, int MODE, bool FAST>
-void launch_one(dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
-                float* dst, float* psum, float* psq, float* slab, const IgemmParams& p) {
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, 2, 2, MODE, FAST>), grid, dim3(256), 0, st, src, apack, table, bias, dst,
-                     psum, psq, slab, p);
+inline void tune_of(const gca_conv_geom* g, int which, int& fbm, int& fs) {
+  if (which == 0) { fbm = g->tune_fwd_bm; fs = g->tune_fwd_splits; }
+  else { fbm = g->tune_dgrad_bm; fs = g->tune_dgrad_splits; }
 }
 
-int run_igemm(int mode, bool fast, const float* src, const float* apack, const int2* table, const float* bias,
+inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, const IgemmParams& p, size_t nclasses) {
+  int fbm, fs;
+  tune_of(g, which, fbm, fs);
+  (void)nclasses;                                   // strided dgrad: one setting for all classes
+  return choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
+}
+
+template <int TM, int BN, bool FAST, bool VEC>
+void launch_one(dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
+                float* dst, float* psum, float* psq, float* slab, const IgemmParams& p) {
+  hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC>), grid, dim3(256), 0, st, src, apack, table, bias,
+                     dst, psum, psq, slab, p);
+}
+
+template <int TM>
+void launch_tm(const IgemmCfg& c, bool fast, dim3 grid, hipStream_t st, const float* src, const float* apack,
+               const int2* table, const float* bias, float* dst, float* psum, float* psq, float* slab,
+               const IgemmParams& p) {
+  if (c.bn == 256) launch_one<TM, 256, true, true>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else if (fast) launch_one<TM, 128, true, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else launch_one<TM, 128, false, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+}
+
+inline int stat_parts(const IgemmCfg& c, long long Ntot) {
+  if (c.splits > 1) return (int)gca_ceil_div(Ntot, FINISH_CHUNK);
+  return (int)gca_ceil_div(Ntot, c.bn) * 4;
+}
+
+int run_class(const IgemmCfg& c, bool fast, const float* src, const float* apack, const int2* table, const float* bias,
               float* dst, float* psum, float* psq, float* slab, IgemmParams p, hipStream_t st) {
-  const IgemmCfg c = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, p.force_bm, p.force_splits);
   p.tilesM = (int)gca_ceil_div(p.DK, c.bm);
-  p.tilesN = (int)gca_ceil_div(p.Ntot, BN);
+  p.tilesN = (int)gca_ceil_div(p.Ntot, c.bn);
   p.splits = c.splits; p.kt_per_split = c.kt_per_split;
-  p.P = c.splits > 1 ? (int)gca_ceil_div(p.Ntot, FINISH_CHUNK) : p.tilesN * 2;
+  p.P = stat_parts(c, p.Ntot);
   if (c.splits > 1 && !slab) return GCA_EINVAL;
   const long long nblk = (long long)p.tilesM * p.tilesN * c.splits;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
   dim3 grid((unsigned)nblk);
   float* ps = c.splits > 1 ? nullptr : psum;
   float* pq = c.splits > 1 ? nullptr : psq;
-  if (c.bm == 64) {
-    if (mode == 1) launch_one<64, 1, false>(grid, st, src, apack, table, bias, dst, ps, pq, slab, p);
-    else if (fast) launch_one<64, 0, true>(grid, st, src, apack, table, bias, dst, ps, pq, slab, p);
-    else launch_one<64, 0, false>(grid, st, src, apack, table, bias, dst, ps, pq, slab, p);
-  } else {
-    if (mode == 1) launch_one<128, 1, false>(grid, st, src, apack, table, bias, dst, ps, pq, slab, p);
-    else if (fast) launch_one<128, 0, true>(grid, st, src, apack, table, bias, dst, ps, pq, slab, p);
-    else launch_one<128, 0, false>(grid, st, src, apack, table, bias, dst, ps, pq, slab, p);
+  switch (c.bm / 32) {
+    case 1: launch_tm<1>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
+    case 2: launch_tm<2>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
+    case 3: launch_tm<3>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
+    case 4: launch_tm<4>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
+    default: launch_tm<5>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
   }
   int rc = gca_launch_status();
   if (rc || c.splits == 1) return rc;
-  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits, bias, dst, psum,
-                     psq, p.DK, p.OD * p.OH * p.OW, p.Ntot, p.accumulate);
+  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits,
+                     bias, dst, psum, psq, p);
   return gca_launch_status();
 }
 
-void fwd_params(const gca_conv_geom* g, IgemmParams& p) {
-  p.NB = g->N; p.SC = g->C; p.SD = g->D; p.SH = g->H; p.SW = g->W; p.DK = g->K;
-  p.OD = g->OD; p.OH = g->OH; p.OW = g->OW;
-  p.m_d = g->sd; p.m_h = g->sh; p.m_w = g->sw; p.o_d = -g->pd; p.o_h = -g->ph; p.o_w = -g->pw;
-  p.kd = g->kd; p.kh = g->kh; p.kw = g->kw; p.tap_sign = 1;
-  p.Kpad = (int)gca_round_up((int64_t)g->C * taps(g), BK);
-  p.Mpad = (int)gca_round_up(g->K, MPAD);
-  p.Ntot = (long long)g->N * g->OD * g->OH * g->OW;
-  // a dimension needs the bounds test unless every window stays inside by construction
-  p.chk = ((g->pd > 0 || (g->OD - 1) * g->sd + g->kd > g->D) ? 1 : 0) |
-          ((g->ph > 0 || (g->OH - 1) * g->sh + g->kh > g->H) ? 2 : 0) |
-          ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
-  p.accumulate = 0;
-  p.src_nstride = g->x_batch_stride ? g->x_batch_stride : (long long)g->C * g->D * g->H * g->W;
-  p.force_bm = g->tune_fwd_bm; p.force_splits = g->tune_fwd_splits;
-}
-
-void dgrad_params(const gca_conv_geom* g, IgemmParams& p, int& mode) {
-  p.NB = g->N; p.SC = g->K; p.SD = g->OD; p.SH = g->OH; p.SW = g->OW; p.DK = g->C;
-  p.OD = g->D; p.OH = g->H; p.OW = g->W;
-  p.m_d = g->sd; p.m_h = g->sh; p.m_w = g->sw; p.o_d = g->pd; p.o_h = g->ph; p.o_w = g->pw;
-  p.kd = g->kd; p.kh = g->kh; p.kw = g->kw; p.tap_sign = -1;
-  p.Kpad = (int)gca_round_up((int64_t)g->K * taps(g), BK);
-  p.Mpad = (int)gca_round_up(g->C, MPAD);
-  p.Ntot = (long long)g->N * g->D * g->H * g->W;
-  p.src_nstride = (long long)g->K * g->OD * g->OH * g->OW;
-  p.force_bm = g->tune_dgrad_bm; p.force_splits = g->tune_dgrad_splits;
-  if (unit_stride(g)) {
-    mode = 0; p.m_d = p.m_h = p.m_w = 1;
-    p.chk = ((g->kd > 1 || g->pd > 0) ? 1 : 0) | ((g->kh > 1 || g->ph > 0) ? 2 : 0) | ((g->kw > 1 || g->pw > 0) ? 4 : 0);
-  } else {
-    mode = 1; p.chk = 7;
+int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  int64_t need = 0;
+  for (const ClassInfo& c : cls) {
+    if (c.ntaps == 0) continue;
+    IgemmParams p{};
+    class_params(g, which, c, p);
+    const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
+    if (cf.splits > 1) {
+      const int64_t b = (int64_t)cf.splits * p.DK * p.Ntot * (int64_t)sizeof(float);
+      if (b > need) need = b;
+    }
   }
+  return need;
 }
 
 }  // namespace
 
 extern "C" {
 
-int gca_version(void) { return 2; }
+int gca_version(void) { return 3; }
 
 int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return GCA_EINVAL;
-  const int64_t kred = (which == 0 ? (int64_t)g->C : (int64_t)g->K) * taps(g);
-  const int64_t m = which == 0 ? g->K : g->C;
-  return gca_round_up(kred, BK) * gca_round_up(m, MPAD);
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  int64_t n = 0;
+  for (const ClassInfo& c : cls) n += c.Kpad * pack_rows(c.M);
+  return n > 0 ? n : 64;
 }
 
 int gca_conv_pack(const gca_conv_geom* g, int which, const float* w, float* packed, void* stream) {
   if (!geom_ok(g) || (which != 0 && which != 1) || !w || !packed) return GCA_EINVAL;
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
   const int T = taps(g);
-  int Kred, M, Tdiv; long long s_kq, s_m;
-  if (which == 0) { Kred = g->C * T; M = g->K; Tdiv = Kred; s_kq = 0; s_m = Kred; }
-  else { Kred = g->K * T; M = g->C; Tdiv = T; s_kq = (long long)g->C * T; s_m = T; }
-  const int Kpad = (int)gca_round_up(Kred, BK), Mpad = (int)gca_round_up(M, MPAD);
-  dim3 grid((unsigned)gca_ceil_div(Kpad, 32), (unsigned)gca_ceil_div(Mpad, 32));
-  hipLaunchKernelGGL(conv_pack_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, packed, Kred, M, Kpad, Mpad,
-                     Tdiv, s_kq, s_m);
+  for (const ClassInfo& c : cls) {
+    if (c.ntaps == 0) continue;
+    PackParams p{};
+    p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = (int)c.Kpad; p.Mrows = pack_rows(c.M);
+    p.ntaps = c.ntaps; p.nb = c.nb; p.nc = c.nc;
+    p.k0d = c.k0[0]; p.k0h = c.k0[1]; p.k0w = c.k0[2]; p.sd = c.ks[0]; p.sh = c.ks[1]; p.sw = c.ks[2];
+    p.KH = g->kh; p.KW = g->kw; p.T = T;
+    if (which == 0) { p.s_ch = T; p.s_m = (long long)g->C * T; }       // W[m=ko][ch=c][tap]
+    else { p.s_ch = (long long)g->C * T; p.s_m = T; }                  // W[ch=ko][m=c][tap]
+    long long blocks = gca_ceil_div((long long)p.Mrows * p.Kpad, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                       packed + c.pack_off, p);
+  }
   return gca_launch_status();
 }
 
 int64_t gca_conv_table_rows(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || which < 0 || which > 2) return GCA_EINVAL;
-  const int64_t kred = (which == 1 ? (int64_t)g->K : (int64_t)g->C) * taps(g);
-  return gca_round_up(kred, which == 2 ? TABLE_PAD_W : BK);
+  if (which == 2) return gca_round_up((int64_t)g->C * taps(g), TABLE_PAD_W);
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  int64_t n = 0;
+  for (const ClassInfo& c : cls) if (c.ntaps) n += c.Kpad + 32;
+  return n > 0 ? n : 32;
 }
 
 int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* t) {
   if (!geom_ok(g) || which < 0 || which > 2 || !t) return GCA_EINVAL;
-  const int T = taps(g);
-  const int64_t rows = gca_conv_table_rows(g, which);
-  const int64_t kred = (which == 1 ? (int64_t)g->K : (int64_t)g->C) * T;
   const int64_t HW = (int64_t)g->H * g->W, DHW = HW * g->D;
-  const int64_t OHW = (int64_t)g->OH * g->OW, OSP = OHW * g->OD;
-  const bool linear_dgrad = unit_stride(g);
-  for (int64_t k = 0; k < rows; ++k) {
-    int32_t off = 0, pk = 63 << 25;          // padded row: invalid, tap id 63
-    if (k < kred) {
-      const int ch = (int)(k / T), tap = (int)(k % T);
-      const int a = tap / (g->kh * g->kw), r = tap % (g->kh * g->kw);
-      const int b = r / g->kw, c = r % g->kw;
-      int dd, dh, dw; int64_t o;
-      if (which == 1) {
-        dd = -a; dh = -b; dw = -c;
-        o = (int64_t)ch * OSP;
-        if (linear_dgrad) o += -(int64_t)a * OHW - (int64_t)b * g->OW - c;
-      } else {
-        dd = a; dh = b; dw = c;
-        o = (int64_t)ch * DHW + (int64_t)a * HW + (int64_t)b * g->W + c;
+  if (which == 2) {                       // wgrad: one row per (c, tap) with the forward deltas
+    const int T = taps(g);
+    const int64_t rows = gca_conv_table_rows(g, 2), kred = (int64_t)g->C * T;
+    for (int64_t k = 0; k < rows; ++k) {
+      int32_t off = 0, pk = pack_row_meta(0, 0, 0, 0, 63);
+      if (k < kred) {
+        const int ch = (int)(k / T), tap = (int)(k % T);
+        const int a = tap / (g->kh * g->kw), r = tap % (g->kh * g->kw), b = r / g->kw, c = r % g->kw;
+        off = (int32_t)(ch * DHW + a * HW + (int64_t)b * g->W + c);
+        pk = pack_row_meta(a, b, c, 1, tap < 63 ? tap : 63);
       }
-      off = (int32_t)o;
-      const int tap6 = tap < 63 ? tap : 63;
-      pk = (dd & 0xff) | ((dh & 0xff) << 8) | ((dw & 0xff) << 16) | (1 << 24) | (tap6 << 25);
+      t[2 * k] = off; t[2 * k + 1] = pk;
     }
-    t[2 * k] = off;
-    t[2 * k + 1] = pk;
+    return GCA_OK;
+  }
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  const int64_t SHW = which == 0 ? HW : (int64_t)g->OH * g->OW;
+  const int64_t SW = which == 0 ? g->W : g->OW;
+  const int64_t SDHW = which == 0 ? DHW : SHW * g->OD;
+  for (const ClassInfo& c : cls) {
+    if (c.ntaps == 0) continue;
+    int32_t* rows = t + 2 * c.table_off;
+    for (int64_t k = 0; k < c.Kpad; ++k) {
+      int32_t off = 0, pk = pack_row_meta(0, 0, 0, 0, 63);
+      if (k < c.Kred) {
+        const int ch = (int)(k / c.ntaps), tl = (int)(k % c.ntaps);
+        const int a = tl / (c.nb * c.nc), r = tl % (c.nb * c.nc), b = r / c.nc, cc = r % c.nc;
+        const int dd = c.dl0[0] + c.dls[0] * a, dh = c.dl0[1] + c.dls[1] * b, dw = c.dl0[2] + c.dls[2] * cc;
+        off = (int32_t)(uint32_t)((uint64_t)((int64_t)(ch * SDHW + dd * SHW + dh * SW + dw) * 4) & 0xffffffffu);   // BYTES
+        pk = pack_row_meta(dd, dh, dw, 1, tl < 63 ? tl : 63);
+      }
+      rows[2 * k] = off; rows[2 * k + 1] = pk;
+    }
+    int32_t* tt = rows + 2 * c.Kpad;       // 64-int tap-delta table for the validity mask
+    for (int tl = 0; tl < 64; ++tl) {
+      int32_t pk = 0;
+      if (tl < c.ntaps && c.ntaps <= FAST_MAX_TAPS) {
+        const int a = tl / (c.nb * c.nc), r = tl % (c.nb * c.nc), b = r / c.nc, cc = r % c.nc;
+        pk = pack_row_meta(c.dl0[0] + c.dls[0] * a, c.dl0[1] + c.dls[1] * b, c.dl0[2] + c.dls[2] * cc, 1, 0);
+      }
+      tt[tl] = pk;
+    }
   }
   return GCA_OK;
 }
 
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
   if (!geom_ok(g) || which < 0 || which > 1 || !out4) return GCA_EINVAL;
-  IgemmParams p{}; int mode = 0;
-  if (which == 0) fwd_params(g, p); else dgrad_params(g, p, mode);
-  const IgemmCfg c = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, p.force_bm, p.force_splits);
-  out4[0] = c.bm; out4[1] = c.splits; out4[2] = mode; out4[3] = (mode == 0 && taps(g) <= FAST_MAX_TAPS) ? 1 : 0;
-  return GCA_OK;
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  for (const ClassInfo& c : cls) {
+    if (c.ntaps == 0) continue;
+    IgemmParams p{};
+    class_params(g, which, c, p);
+    const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | ((c.ntaps <= FAST_MAX_TAPS) << 8) | (c.vec << 9);
+    return GCA_OK;
+  }
+  return GCA_EINVAL;
 }
 
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g) {
   if (!geom_ok(g)) return GCA_EINVAL;
+  std::vector<ClassInfo> cls;
+  build_classes(g, 0, cls);
   IgemmParams p{};
-  fwd_params(g, p);
-  const IgemmCfg c = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, p.force_bm, p.force_splits);
-  return c.splits > 1 ? gca_ceil_div(p.Ntot, FINISH_CHUNK) : gca_ceil_div(p.Ntot, BN) * 2;
+  class_params(g, 0, cls[0], p);
+  return stat_parts(cfg_for(g, 0, cls[0], p, 1), p.Ntot);
 }
 
-int64_t gca_conv_fwd_ws_bytes(const gca_conv_geom* g) {
-  if (!geom_ok(g)) return GCA_EINVAL;
-  IgemmParams p{};
-  fwd_params(g, p);
-  const IgemmCfg c = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, p.force_bm, p.force_splits);
-  return c.splits > 1 ? (int64_t)c.splits * p.DK * p.Ntot * (int64_t)sizeof(float) : 0;
-}
-
-int64_t gca_conv_dgrad_ws_bytes(const gca_conv_geom* g) {
-  if (!geom_ok(g)) return GCA_EINVAL;
-  IgemmParams p{}; int mode;
-  dgrad_params(g, p, mode);
-  const IgemmCfg c = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, p.force_bm, p.force_splits);
-  return c.splits > 1 ? (int64_t)c.splits * p.DK * p.Ntot * (int64_t)sizeof(float) : 0;
-}
+int64_t gca_conv_fwd_ws_bytes(const gca_conv_geom* g) { return geom_ok(g) ? ws_bytes_for(g, 0) : GCA_EINVAL; }
+int64_t gca_conv_dgrad_ws_bytes(const gca_conv_geom* g) { return geom_ok(g) ? ws_bytes_for(g, 1) : GCA_EINVAL; }
 
 int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, const int32_t* table,
                  const float* bias, float* y, float* stat_sum, float* stat_sq, void* ws, void* stream) {
   if (!geom_ok(g) || !x || !wpack || !table || !y) return GCA_EINVAL;
   if ((stat_sum == nullptr) != (stat_sq == nullptr)) return GCA_EINVAL;
+  std::vector<ClassInfo> cls;
+  build_classes(g, 0, cls);
+  const ClassInfo& c = cls[0];
   IgemmParams p{};
-  fwd_params(g, p);
-  return run_igemm(0, taps(g) <= FAST_MAX_TAPS, x, wpack, reinterpret_cast<const int2*>(table), bias, y, stat_sum,
-                   stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
+  class_params(g, 0, c, p);
+  p.accumulate = 0;
+  return run_class(cfg_for(g, 0, c, p, 1), c.ntaps <= FAST_MAX_TAPS, x, wpack, reinterpret_cast<const int2*>(table), bias,
+                   y, stat_sum, stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
 }
 
 int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, const int32_t* table,
                    float* dx, int accumulate, void* ws, void* stream) {
   if (!geom_ok(g) || !dy || !wpack || !table || !dx) return GCA_EINVAL;
   if (g->x_batch_stride != 0 && g->x_batch_stride != (long long)g->C * g->D * g->H * g->W) return GCA_EINVAL;
-  IgemmParams p{}; int mode;
-  dgrad_params(g, p, mode);
-  p.accumulate = accumulate ? 1 : 0;
-  return run_igemm(mode, mode == 0 && taps(g) <= FAST_MAX_TAPS, dy, wpack, reinterpret_cast<const int2*>(table),
-                   nullptr, dx, nullptr, nullptr, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
-}
-
-static void wgrad_plan(const gca_conv_geom* g, WgradParams& p, bool& bm64, bool& bn64) {
-  p.NB = g->N; p.C = g->C; p.D = g->D; p.H = g->H; p.W = g->W; p.K = g->K;
-  p.OD = g->OD; p.OH = g->OH; p.OW = g->OW;
-  p.sd = g->sd; p.sh = g->sh; p.sw = g->sw; p.pd = g->pd; p.ph = g->ph; p.pw = g->pw;
-  p.Kred = g->C * taps(g);
-  p.Ktot = (long long)g->N * g->OD * g->OH * g->OW;
-  p.x_nstride = g->x_batch_stride ? g->x_batch_stride : (long long)g->C * g->D * g->H * g->W;
-  auto small = [](int dk) {
-    if (dk <= 64) return true;
-    const int t128 = (int)gca_ceil_div(dk, 128) * 128, t64 = (int)gca_ceil_div(dk, 64) * 64;
-    return (t128 - dk) * 4 > t128 && t64 < t128;
-  };
-  bm64 = small(g->K);
-  bn64 = small(p.Kred);
-  p.tilesM = (int)gca_ceil_div(g->K, bm64 ? 64 : 128);
-  p.tilesN = (int)gca_ceil_div(p.Kred, bn64 ? 64 : 128);
-  p.kt_total = (int)gca_ceil_div(p.Ktot, WBK);
-  const long long tiles = (long long)p.tilesM * p.tilesN;
-  long long want = gca_ceil_div(1024, tiles);                 // aim for ~4 workgroups per CU
-  long long maxs = p.kt_total / 4 > 0 ? p.kt_total / 4 : 1;   // >= 4 k-tiles per split
-  if (want > maxs) want = maxs;
-  if (want > 512) want = 512;
-  if (want < 1) want = 1;
-  if (g->tune_wgrad_splits > 0) want = g->tune_wgrad_splits < p.kt_total ? g->tune_wgrad_splits : p.kt_total;
-  p.kt_per_split = (int)gca_ceil_div(p.kt_total, want);
-  p.splits = (int)gca_ceil_div(p.kt_total, p.kt_per_split);
-  p.chk = ((g->pd > 0 || (g->OD - 1) * g->sd + g->kd > g->D) ? 1 : 0) |
-          ((g->ph > 0 || (g->OH - 1) * g->sh + g->kh > g->H) ? 2 : 0) |
-          ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
-}
-
-int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g) {
-  if (!geom_ok(g)) return GCA_EINVAL;
-  WgradParams p{}; bool a, b;
-  wgrad_plan(g, p, a, b);
-  return (int64_t)p.splits * g->K * p.Kred * (int64_t)sizeof(float);
-}
-
-int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
-                   float* dw, int accumulate, void* ws, void* stream) {
-  if (!geom_ok(g) || !x || !dy || !table || !dw || !ws) return GCA_EINVAL;
-  WgradParams p{}; bool bm64, bn64;
-  wgrad_plan(g, p, bm64, bn64);
   hipStream_t st = (hipStream_t)stream;
-  const long long nblk = (long long)p.tilesM * p.tilesN * p.splits;
-  if (nblk > 0x7fffffffLL) return GCA_EINVAL;
-  const int2* t = reinterpret_cast<const int2*>(table);
-  float* slab = reinterpret_cast<float*>(ws);
-  dim3 grid((unsigned)nblk), blk(256);
-  if (bm64 && bn64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, blk, 0, st, x, dy, t, slab, p);
-  else if (bm64) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, blk, 0, st, x, dy, t, slab, p);
-  else if (bn64) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, blk, 0, st, x, dy, t, slab, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, blk, 0, st, x, dy, t, slab, p);
-  int rc = gca_launch_status();
-  if (rc) return rc;
-  const long long n = (long long)g->K * p.Kred;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 256)), dim3(256), 0, st, slab, dw, n,
-                     p.splits, accumulate ? 1 : 0);
-  return gca_launch_status();
-}
-
-int gca_bias_grad(const float* dy, int64_t N, int64_t K, int64_t SP, float* db, int accumulate, void* stream) {
-  if (!dy || !db || N <= 0 || K <= 0 || SP <= 0) return GCA_EINVAL;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)K), dim3(256), 0, (hipStream_t)stream, dy, (long long)N,
-                     (long long)K, (long long)SP, db, accumulate ? 1 : 0);
-  return gca_launch_status();
+  std::vector<ClassInfo> cls;
+  build_classes(g, 1, cls);
+  bool any_empty = false;
+  for (const ClassInfo& c : cls) any_empty |= c.ntaps == 0;
+  if (any_empty && !accumulate) {          // positions no tap reaches (e.g. 1x1x1 stride 2) get an exact zero
+    const long long n = (long long)g->N * g->C * g->D * g->H * g->W;
+    long long blocks = gca_ceil_div(n, 1024);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dx, n);
+  }
+  const int2* tab = reinterpret_cast<const int2*>(table);
+  for (const ClassInfo& c : cls) {
+    if (c.ntaps == 0) continue;
+    IgemmParams p{};
+    class_params(g, 1, c, p);
+    p.accumulate = accumulate ? 1 : 0;
+    int rc = run_class(cfg_for(g, 1, c, p, cls.size()), c.ntaps <= FAST_MAX_TAPS, dy, wpack + c.pack_off,
+                       tab + c.table_off, nullptr, dx, nullptr, nullptr, reinterpret_cast<float*>(ws), p, st);
+    if (rc) return rc;
+  }
+  return GCA_OK;
 }
 
 }  // extern "C"

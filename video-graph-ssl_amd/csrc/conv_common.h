@@ -1,0 +1,54 @@
+// Shared by conv3d.hip (forward / dgrad implicit GEMM) and conv3d_wgrad.hip.
+#pragma once
+#include "gca_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace gca_conv {
+
+constexpr int BK = 16;          // GEMM-K tile of the forward/dgrad kernels
+constexpr int WBK = 32;         // GEMM-K (spatial) tile of the wgrad kernel
+constexpr int MPAD = 64;        // packed weights: M padded to this
+constexpr int TABLE_PAD_W = 128;
+constexpr int FAST_MAX_TAPS = 62;
+constexpr int NUM_CU = 256;
+
+// row table entry: x = element offset; y = dd | dh<<8 | dw<<16 (signed bytes) | valid<<24 | tap6<<25
+__device__ __forceinline__ void decode_row(int2 e, int& off, int& dd, int& dh, int& dw, int& valid) {
+  off = e.x;
+  dd = (e.y << 24) >> 24;
+  dh = (e.y << 16) >> 24;
+  dw = (e.y << 8) >> 24;
+  valid = (e.y >> 24) & 1;
+}
+inline int pack_row_meta(int dd, int dh, int dw, int valid, int tap6) {
+  return (dd & 0xff) | ((dh & 0xff) << 8) | ((dw & 0xff) << 16) | ((valid & 1) << 24) | ((tap6 & 63) << 25);
+}
+
+inline bool geom_ok(const gca_conv_geom* g) {
+  if (!g) return false;
+  if (g->N <= 0 || g->C <= 0 || g->D <= 0 || g->H <= 0 || g->W <= 0 || g->K <= 0) return false;
+  if (g->kd <= 0 || g->kh <= 0 || g->kw <= 0 || g->sd <= 0 || g->sh <= 0 || g->sw <= 0) return false;
+  if (g->pd < 0 || g->ph < 0 || g->pw < 0) return false;
+  if (g->kd > 127 || g->kh > 127 || g->kw > 127) return false;
+  const int od = (g->D + 2 * g->pd - g->kd) / g->sd + 1;
+  const int oh = (g->H + 2 * g->ph - g->kh) / g->sh + 1;
+  const int ow = (g->W + 2 * g->pw - g->kw) / g->sw + 1;
+  if (od != g->OD || oh != g->OH || ow != g->OW || od <= 0 || oh <= 0 || ow <= 0) return false;
+  // the kernels address both tensors with 32-bit byte offsets from their base: < 2^30 elements (4 GiB) each
+  const long long cdhw = (long long)g->C * g->D * g->H * g->W;
+  if (g->x_batch_stride != 0 && g->x_batch_stride < cdhw) return false;
+  const long long in_elems = (long long)g->N * (g->x_batch_stride ? g->x_batch_stride : cdhw);
+  const long long out_elems = (long long)g->N * g->K * od * oh * ow;
+  if (in_elems >= (1LL << 30) || out_elems >= (1LL << 30)) return false;
+  for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && (v >> 10) <= 1)) return false;
+  for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
+  return true;
+}
+
+inline int taps(const gca_conv_geom* g) { return g->kd * g->kh * g->kw; }
+inline bool unit_stride(const gca_conv_geom* g) { return g->sd == 1 && g->sh == 1 && g->sw == 1; }
+
+
+}  // namespace gca_conv

@@ -103,17 +103,22 @@ class ConvPlan:
 
     # ---- one-off launch tuning ------------------------------------------------------------
     def _igemm_candidates(self, M, Ntot, kred):
+        """(tile code, split) pairs: tile code = rows (32..160) | 1024 for the 256-column float4 variant."""
         nk = -(-kred // 16)
-        tn = -(-Ntot // 128)
+        g = self.g
+        pointwise = g.kh == 1 and g.kw == 1 and g.sh == 1 and g.sw == 1 and g.ph == 0 and g.pw == 0
         cands = []
-        for bm in (64, 128):
-            if bm == 128 and M <= 64:
-                continue
-            tiles = -(-M // bm) * tn
-            for s in (1, 2, 3, 4, 6, 8, 12, 16):
-                if s > 1 and (tiles >= 1024 or nk // s < 4 or s * M * Ntot * 4 > (96 << 20)):
+        for vec in ((0, 1024) if pointwise else (0,)):
+            bn = 256 if vec else 128
+            for bm in (32, 64, 96, 128, 160):
+                padded = -(-M // bm) * bm
+                if padded > 1.35 * max(M, 32) and bm > 32:       # skip tile heights that mostly multiply zeros
                     continue
-                cands.append((bm, s))
+                tiles = -(-M // bm) * -(-Ntot // bn)
+                for s in (1, 2, 3, 4, 6, 8, 12, 16):
+                    if s > 1 and (tiles >= 1024 or nk // s < 4 or s * M * Ntot * 4 > (96 << 20)):
+                        continue
+                    cands.append((bm | vec, s))
         return cands
 
     def tune(self, which, run):
