@@ -241,7 +241,10 @@ int gca_sgd_step(float* p, const float* grad, float* mom_buf, int64_t n, const f
 int gca_fill(float* p, int64_t n, float v, void* stream);
 int gca_axpy(float* y, const float* x, int64_t n, float a, void* stream);          /* y += a*x */
 int gca_scale(float* y, int64_t n, float a, void* stream);
-int gca_gather_rows(const float* src, const int64_t* idx, int64_t rows, int64_t row_elems, float* dst, void* stream);
+/* dst[r,:] = src[idx[r]*src_row_stride : +row_elems]; rows <= 65535.  src rows may be strided (the key view of a
+ * (b,6,T,H,W) batch is gathered in place for the ShuffleBN exchange, tools/...dis.py:404,213-217). */
+int gca_gather_rows(const float* src, const int64_t* idx, int64_t rows, int64_t row_elems, int64_t src_row_stride,
+                    float* dst, void* stream);
 
 #ifdef __cplusplus
 }

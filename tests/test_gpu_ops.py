@@ -354,3 +354,16 @@ def test_ema_sgd_multitensor(ops):
         ops.sgd_step(pd, gstep.to(DEV), buf, lr.to(DEV), wd.to(DEV), 1.0, 0.9, False)
     want = torch.cat([gp['params'][0].data for gp in groups])
     assert rel_err(pd, want) < 1e-6
+
+
+def test_gather_rows_contiguous_and_batch_strided_view(ops):
+    """ShuffleBN gathers the key view of the (b,6,T,H,W) batch in place (tools/...dis.py:404,213-217)."""
+    torch.manual_seed(5)
+    img = torch.randn(6, 6, 2, 5, 7, device=DEV)
+    idx = torch.tensor([4, 0, 5, 5, 2], device=DEV)
+    x2 = torch.chunk(img, 2, dim=1)[1]
+    assert torch.equal(ops.gather_rows(x2, idx), x2[idx])
+    flat = torch.randn(9, 130, device=DEV)                      # float4 rows
+    assert torch.equal(ops.gather_rows(flat, idx), flat[idx])
+    odd = torch.randn(9, 3, device=DEV)                         # scalar rows
+    assert torch.equal(ops.gather_rows(odd, idx), odd[idx])

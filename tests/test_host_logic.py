@@ -36,7 +36,7 @@ def test_geometry_validation_without_gpu(pkg):
     H = pkg._hip
     import ctypes as C
     good = H.ConvGeom(2, 3, 4, 8, 8, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, 4, 8, 8, 0)
-    assert H.lib.gca_conv_pack_elems(C.byref(good), 0) == 32 * 64          # K = 27 -> 32, M = 5 -> 64
+    assert H.lib.gca_conv_pack_elems(C.byref(good), 0) == (32 + 128) * 32   # K = 27 -> 32; M = 5 -> 32 rows + 128 zero rows (tallest tile may overhang)
     assert H.lib.gca_conv_table_rows(C.byref(good), 1) == 48 + 32          # 5 * 9 = 45 -> 48 rows + tap-delta table
     bad = H.ConvGeom(2, 3, 4, 8, 8, 5, 1, 3, 3, 1, 1, 1, 0, 1, 1, 4, 8, 7, 0)   # wrong OW
     assert H.lib.gca_conv_pack_elems(C.byref(bad), 0) == -1
@@ -44,8 +44,8 @@ def test_geometry_validation_without_gpu(pkg):
     tab = torch.zeros(rows * 2, dtype=torch.int32)
     assert H.lib.gca_conv_table_build_host(C.byref(good), 0, tab.data_ptr()) == 0
     t = tab.view(rows, 2)
-    # row k = (c, kh, kw): offset c*D*H*W + kh*W + kw ; padded rows are invalid with tap id 63
-    assert int(t[0, 0]) == 0 and int(t[4, 0]) == 1 * 8 + 1 and int(t[9, 0]) == 4 * 8 * 8
+    # row k = (c, kh, kw): BYTE offset 4*(c*D*H*W + kh*W + kw) ; padded rows are invalid with tap id 63
+    assert int(t[0, 0]) == 0 and int(t[4, 0]) == 4 * (1 * 8 + 1) and int(t[9, 0]) == 4 * (4 * 8 * 8)
     assert (int(t[26, 1]) >> 24) & 1 == 1 and (int(t[27, 1]) >> 24) & 1 == 0 and (int(t[27, 1]) >> 25) & 63 == 63
 
 

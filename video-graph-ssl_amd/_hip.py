@@ -93,7 +93,7 @@ SIGNATURES = {
     'gca_fill': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
     'gca_axpy': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     'gca_scale': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
-    'gca_gather_rows': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'gca_gather_rows': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header/library drift

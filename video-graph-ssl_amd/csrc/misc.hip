@@ -1,6 +1,7 @@
 // Head pieces (ReLU, row L2-normalise, negative cosine) and the multi-tensor parameter updates
 // (EMA key-encoder update, SGD) over flat parameter arenas.  All HBM-bound float4 streaming.
 // Reference call sites: see include/gca_hip.h.
+#include <cstdint>
 #include "gca_common.h"
 
 namespace {
@@ -129,12 +130,20 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 __global__ void scale_kernel(float* __restrict__ y, long long n, float a) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] *= a;
 }
-__global__ void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, long long rows,
-                                   long long re, float* __restrict__ dst) {
-  const long long total = rows * re;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const long long r = i / re, c = i - r * re;
-    dst[i] = src[idx[r] * re + c];
+// dst[r, :] = src[idx[r] * src_stride : +re]  -- one grid row per gathered row, float4 when alignment allows.
+template <int V>
+__global__ void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx, long long re,
+                                   long long src_stride, float* __restrict__ dst) {
+  const long long r = blockIdx.y;
+  const float* s = src + idx[r] * src_stride;
+  float* d = dst + r * re;
+  const long long step = (long long)gridDim.x * blockDim.x;
+  if (V == 4) {
+    const long long n4 = re >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += step)
+      reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+  } else {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < re; i += step) d[i] = s[i];
   }
 }
 
@@ -206,10 +215,19 @@ int gca_scale(float* y, int64_t n, float a, void* stream) {
   hipLaunchKernelGGL(scale_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, (long long)n, a);
   return gca_launch_status();
 }
-int gca_gather_rows(const float* src, const int64_t* idx, int64_t rows, int64_t row_elems, float* dst, void* stream) {
-  if (!src || !idx || !dst || rows <= 0 || row_elems <= 0) return GCA_EINVAL;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(ew_blocks(rows * row_elems)), dim3(256), 0, (hipStream_t)stream, src,
-                     (const long long*)idx, (long long)rows, (long long)row_elems, dst);
+int gca_gather_rows(const float* src, const int64_t* idx, int64_t rows, int64_t row_elems, int64_t src_row_stride,
+                    float* dst, void* stream) {
+  if (!src || !idx || !dst || rows <= 0 || rows > 65535 || row_elems <= 0 || src_row_stride < row_elems) return GCA_EINVAL;
+  const bool v4 = row_elems % 4 == 0 && src_row_stride % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0;
+  const long long per = v4 ? row_elems / 4 : row_elems;
+  long long bx = gca_ceil_div(per, 256 * 4);
+  if (bx < 1) bx = 1;
+  if (bx > 1024) bx = 1024;
+  const dim3 grid((unsigned)bx, (unsigned)rows);
+  if (v4) hipLaunchKernelGGL(gather_rows_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, src, (const long long*)idx,
+                             (long long)row_elems, (long long)src_row_stride, dst);
+  else hipLaunchKernelGGL(gather_rows_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, (const long long*)idx,
+                          (long long)row_elems, (long long)src_row_stride, dst);
   return gca_launch_status();
 }
 

@@ -481,8 +481,11 @@ def scale_(y, a):
 
 
 def gather_rows(src, idx):
+    """dst[r] = src[idx[r]] over dim 0.  src may be a batch-strided view (each row itself contiguous)."""
     rows = idx.numel()
-    re = src.numel() // src.shape[0]
+    re = src[0].numel()
+    if not src[0].is_contiguous() or idx.dtype != torch.long:
+        raise ValueError('gather_rows: rows must be contiguous, idx int64')
     dst = torch.empty((rows,) + tuple(src.shape[1:]), dtype=F32, device=src.device)
-    H.call('gca_gather_rows', ptr(src), ptr(idx), rows, re, ptr(dst), stream())
+    H.call('gca_gather_rows', ptr(src), ptr(idx), rows, re, src.stride(0) if src.shape[0] > 1 else re, ptr(dst), stream())
     return dst

@@ -22,8 +22,12 @@ import torch.distributed as dist
 
 
 class DistCtx(object):
-    def __init__(self, rank=0, world=1, group=None):
-        self.rank, self.world, self.group = rank, world, group
+    """rank / world / process group.  `host_staged` routes device tensors through pinned host memory around
+    each collective: that is how the N>1 code path is rehearsed with the gloo backend when the ranks share
+    one GPU (tests/test_gpu_dist.py); production (backend "nccl" = RCCL) leaves it False."""
+
+    def __init__(self, rank=0, world=1, group=None, host_staged=False):
+        self.rank, self.world, self.group, self.host_staged = rank, world, group, bool(host_staged)
 
     @property
     def active(self):
@@ -68,8 +72,14 @@ def shuffle_exchange(x, shuffle_ids, ctx, gather):
     send_idx, send_counts, recv_counts, place_idx = exchange_plan(shuffle_ids, b, ctx.rank, ctx.world)
     send = gather(x, send_idx.to(x.device)) if send_idx.numel() else x[:0]
     recv = torch.empty((b,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                           group=ctx.group)
+    if ctx.host_staged:
+        recv_h = torch.empty(recv.shape, dtype=x.dtype)
+        dist.all_to_all_single(recv_h, send.contiguous().cpu(), output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=ctx.group)
+        recv.copy_(recv_h)
+    else:
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                               group=ctx.group)
     return gather(recv, place_idx.to(x.device))
 
 
@@ -78,7 +88,12 @@ def gather_keys(k, ctx):
     if not ctx.active:
         return k
     out = torch.empty((ctx.world * k.shape[0],) + tuple(k.shape[1:]), dtype=k.dtype, device=k.device)
-    dist.all_gather_into_tensor(out, k.contiguous(), group=ctx.group)
+    if ctx.host_staged:
+        parts = [torch.empty(k.shape, dtype=k.dtype) for _ in range(ctx.world)]
+        dist.all_gather(parts, k.contiguous().cpu(), group=ctx.group)
+        out.copy_(torch.cat(parts))
+    else:
+        dist.all_gather_into_tensor(out, k.contiguous(), group=ctx.group)
     return out
 
 
@@ -93,12 +108,22 @@ def allreduce_sum_(flat, ctx):
     """Gradient all-reduce over the flat arena (SUM; the 1/world of DDP's mean is folded into the loss
     gradient scale by the trainer, so no extra pass over the buffer)."""
     if ctx.active:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
+        if ctx.host_staged:
+            h = flat.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=ctx.group)
+            flat.copy_(h)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=ctx.group)
     return flat
 
 
 def broadcast_(t, ctx, src=0):
     """Initial queue / parameter sync (:233-241)."""
     if ctx.active:
-        dist.broadcast(t, src, group=ctx.group)
+        if ctx.host_staged:
+            h = t.cpu()
+            dist.broadcast(h, src, group=ctx.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src, group=ctx.group)
     return t
