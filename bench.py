@@ -258,6 +258,11 @@ def main():
                              '--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    # GCA_BENCH_REHEARSAL=1: every rank on cuda:0, gloo + host-staged collectives -- a functional rehearsal of
+    # the N>1 flow on a one-GPU box (numbers from it are meaningless and the JSON line says so).
+    rehearsal = os.environ.get('GCA_BENCH_REHEARSAL', '0') == '1' and world > 1
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     pkg = importlib.import_module('video-graph-ssl_amd')
@@ -265,8 +270,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)      # "nccl" == RCCL on ROCm
-        ctx = pkg.parallel.DistCtx(rank, world, None)
+        if rehearsal:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world,      # "nccl" == RCCL on ROCm
+                                    device_id=dev)
+        ctx = pkg.parallel.DistCtx(rank, world, None, host_staged=rehearsal)
     K = args.queue or (4096 if world == 1 else 65536)
     cfg = make_cfg(pkg, args, K)
     tr = pkg.MoCoTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
@@ -297,10 +306,13 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device='cpu' if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = float(out['loss'].item())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     log('timed region %.3fs, loss %.4f' % (dt, loss))
@@ -315,7 +327,7 @@ def main():
                                'queue K=%d, T=0.07, SGD+EMA (BASELINE.json configs[%d])'
                                % (args.backbone, args.frames, args.size, args.size, args.batch, global_batch, K,
                                   1 if world == 1 else 2),
-                   'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph},
+                   'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, **({'rehearsal': 'gloo/host-staged on one GPU: NOT a measurement'} if rehearsal else {})},
         'views_per_sec': round(2 * value, 3), 'final_loss': round(loss, 5),
     }
     if step_gflop:
@@ -324,9 +336,10 @@ def main():
         res['infonce_fwd'] = infonce_timing(pkg, 32)
         log('infonce timing done')
         res['infonce_fwd_ms'] = res['infonce_fwd']['K4096']['ms']
-        if not args.no_kernel_timing:
-            res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
-            log('kernel timing done')
+    if not args.no_kernel_timing:
+        res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
+        log('kernel timing done')
+    if world == 1:
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, K)
     print(json.dumps(res))
