@@ -64,6 +64,19 @@ typedef struct {
 int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which);
 int gca_conv_pack(const gca_conv_geom* g, int which, const float* w, float* packed, void* stream);
 
+/* Batched form of gca_conv_pack for a whole encoder (one launch instead of one per layer and problem class;
+ * the reference re-reads nn.Conv3d.weight in place, so this is part of what replaces cuDNN's per-call filter
+ * transform).  gca_conv_pack_jobs_host writes one GCA_PACK_JOB_BYTES record per problem class of (g, which)
+ * for weights `w` (device) -> `packed` (device) into HOST memory `jobs_out` and returns the number of records
+ * (pass jobs_out = NULL to only count).  The caller concatenates the records of all layers, calls
+ * gca_conv_pack_jobs_finalize_host on the concatenation (assigns each job its block range; returns the grid
+ * size), copies the records to the device once, and replays gca_conv_pack_batched every step; the weight and
+ * packed pointers must stay valid. */
+#define GCA_PACK_JOB_BYTES 128
+int64_t gca_conv_pack_jobs_host(const gca_conv_geom* g, int which, const float* w, float* packed, void* jobs_out);
+int64_t gca_conv_pack_jobs_finalize_host(void* jobs, int64_t njobs);
+int gca_conv_pack_batched(const void* jobs_dev, int64_t njobs, int64_t total_blocks, void* stream);
+
 /* Gather table (one int2 per packed k-row: element offset + packed tap deltas); built on the
  * host once per geometry.  which as above, 2 = wgrad (same rows as forward). */
 int64_t gca_conv_table_rows(const gca_conv_geom* g, int which);

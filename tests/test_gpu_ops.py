@@ -367,3 +367,65 @@ def test_gather_rows_contiguous_and_batch_strided_view(ops):
     assert torch.equal(ops.gather_rows(flat, idx), flat[idx])
     odd = torch.randn(9, 3, device=DEV)                         # scalar rows
     assert torch.equal(ops.gather_rows(odd, idx), odd[idx])
+
+
+@pytest.mark.parametrize('shape,k,s,p', [
+    ((2, 5, 9, 14, 15), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # R(2+1)D / 3D-ResNet stem pool (unrolled 3x3x3, cover 2x2x2)
+    ((2, 3, 4, 13, 11), (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # S3D spatial pools
+    ((2, 3, 5, 7, 9), (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # S3D Mixed_* branch pool (cover 3x3x3)
+    ((2, 3, 6, 8, 10), (2, 2, 2), (2, 2, 2), (0, 0, 0)),      # non-overlapping
+    ((1, 2, 7, 9, 12), (3, 1, 1), (2, 1, 1), (1, 0, 0)),      # S3D temporal pool -> run-time window path
+    ((1, 2, 9, 11, 10), (5, 4, 2), (2, 3, 1), (2, 1, 1)),     # odd generic geometry
+])
+def test_maxpool_random_vs_aten_with_ties(ops, shape, k, s, p):
+    """Values are quantised so windows hold many equal maxima: the argmax tie break (first in d,h,w order) and
+    with it the gradient routing must equal ATen's (s3d_1.py / resnet2p1d.py MaxPool3d call sites)."""
+    torch.manual_seed(7)
+    x = (torch.randn(shape) * 2).round() / 2
+    xr = x.clone().requires_grad_(True)
+    yr, ir = F.max_pool3d(xr, k, s, p, return_indices=True)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    plan = ops.pool_plan(shape, k, s, p)
+    y, am = ops.maxpool_fwd(plan, x.to(DEV))
+    assert torch.equal(y.cpu(), yr.detach())
+    assert torch.equal(am.cpu().long(), ir)
+    dx = ops.maxpool_bwd(plan, dy.to(DEV), am)
+    assert rel_err(dx, xr.grad) < 1e-6
+    base = torch.randn(shape)
+    dx2 = ops.maxpool_bwd(plan, dy.to(DEV), am, base.clone().to(DEV), True)
+    assert rel_err(dx2, base + xr.grad) < 1e-6
+
+
+def test_batched_weight_pack_equals_per_layer_pack(pkg, ops):
+    """gca_conv_pack_batched (one launch per encoder) must write exactly what gca_conv_pack writes per layer."""
+    L = pkg.engine.layers
+    torch.manual_seed(8)
+    net = torch.nn.ModuleList([L.HipConv3d(5, 70, (1, 3, 3), (1, 2, 2), (0, 1, 1)), L.HipConv3d(70, 33, (3, 1, 1), 1, (1, 0, 0)),
+                               L.HipConv3d(33, 200, 1, (2, 2, 2), 0), L.HipLinear(40, 130)]).to(DEV)
+    x = torch.randn(2, 5, 4, 12, 12, device=DEV)
+    refs = []
+    for m in list(net)[:3]:
+        plan = m.plan(x)
+        refs += [m.packed(plan, 0).clone(), m.packed(plan, 1).clone()]
+        x = ops.conv_fwd(plan, x, m._pack[0])
+    lin = net[3]
+    lp = lin.plan(6, DEV)
+    refs += [lin.packed(lp, 0).clone(), lin.packed(lp, 1).clone()]
+    packer = L.BatchedPacker(net, (0, 1))
+    assert packer.n > 8               # 4 layers x 2 directions, and the strided (1,3,3) dgrad has 4 problem classes
+    for m in net:
+        for w in (0, 1):
+            m._pack[w].fill_(float('nan'))
+    packer.run()
+    got = []
+    for m in net:
+        got += [m._pack[0], m._pack[1]]
+    for a, b in zip(got, refs):
+        assert torch.equal(a, b)
+    # layers skip their own packing while the batch is live, and pack again after release()
+    with torch.no_grad():
+        net[0].weight.mul_(2.0)
+    assert torch.equal(net[0].packed(net[0]._pack_plan[0], 0), refs[0])
+    packer.release()
+    assert torch.equal(net[0].packed(net[0]._pack_plan[0], 0), refs[0] * 2.0)

@@ -93,11 +93,17 @@ SIGNATURES = {
     'gca_fill': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
     'gca_axpy': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     'gca_scale': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
+    'gca_conv_pack_jobs_host': (c_i64, [_GP, c_i32, c_vp, c_vp, c_vp]),
+    'gca_conv_pack_jobs_finalize_host': (c_i64, [c_vp, c_i64]),
+    'gca_conv_pack_batched': (c_i32, [c_vp, c_i64, c_i64, c_vp]),
     'gca_gather_rows': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
 }
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)          # AttributeError here = header/library drift
     _fn.restype, _fn.argtypes = _res, _args
+
+
+PACK_JOB_BYTES = 128      # GCA_PACK_JOB_BYTES
 
 
 def ptr(t):

@@ -64,9 +64,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ psum, const float* __restrict__ psq, long long P, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean,
-    float* __restrict__ sinvstd, float* __restrict__ scale, float* __restrict__ shift) {
+    float* __restrict__ sinvstd, float* __restrict__ scale, float* __restrict__ shift, long long* __restrict__ nbt) {
   __shared__ double sh[4];
   const int c = blockIdx.x;
+  if (nbt && c == 0 && threadIdx.x == 0) *nbt += 1;          // num_batches_tracked (BatchNorm bookkeeping)
   double s = 0.0, q = 0.0;
   for (long long i = threadIdx.x; i < P; i += 256) { s += (double)psum[c * P + i]; q += (double)psq[c * P + i]; }
   s = gca_block_sum256_d(s, sh);
@@ -89,8 +90,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     shift[c] = b - (float)m * sc;
   }
 }
-
-__global__ void bn_counter_kernel(long long* nbt) { if (threadIdx.x == 0 && blockIdx.x == 0) *nbt += 1; }
 
 __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
                                     long long C, float* scale, float* shift) {
@@ -225,9 +224,7 @@ int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int6
   if (!stat_sum || !stat_sq || P <= 0 || C <= 0 || count <= 0 || !scale || !shift) return GCA_EINVAL;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, stat_sum, stat_sq,
                      (long long)P, count, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
-                     save_invstd, scale, shift);
-  if (num_batches_tracked)
-    hipLaunchKernelGGL(bn_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)num_batches_tracked);
+                     save_invstd, scale, shift, (long long*)num_batches_tracked);
   return gca_launch_status();
 }
 

@@ -26,6 +26,7 @@
 // also emits the BatchNorm sums).
 //
 // Reference call sites replaced: every nn.Conv3d / nn.Linear on the path (see include/gca_hip.h).
+#include <cstring>
 #include "conv_common.h"
 
 #include <cstdlib>
@@ -364,9 +365,9 @@ struct PackParams {
   int KH, KW, T;               // full kernel
   long long s_ch, s_m;         // element strides of `ch` and `m` in W
 };
-__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, PackParams p) {
-  const long long total = (long long)p.Mrows * p.Kpad;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_elements(const float* __restrict__ w, float* __restrict__ packed,
+                                              const PackParams& p, long long first, long long step, long long end) {
+  for (long long i = first; i < end; i += step) {
     const int m = (int)(i / p.Kpad), k = (int)(i - (long long)m * p.Kpad);
     float v = 0.f;
     if (m < p.M && k < p.Kred) {
@@ -377,6 +378,38 @@ __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict_
     }
     packed[i] = v;
   }
+}
+__global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, PackParams p) {
+  pack_elements(w, packed, p, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x,
+                (long long)p.Mrows * p.Kpad);
+}
+
+// All convolutions of an encoder in ONE launch.  A job is one problem class of one layer; jobs own consecutive
+// block ranges (PACK_CHUNK elements per block) so big and small layers are balanced; a block finds its job by
+// binary search over first_block.
+constexpr int PACK_CHUNK = 2048;
+struct PackJob {
+  PackParams p;
+  const float* w;
+  float* packed;
+  int first_block, nblocks;
+};
+static_assert(sizeof(PackJob) <= GCA_PACK_JOB_BYTES, "gca_hip.h: GCA_PACK_JOB_BYTES too small");
+__global__ __launch_bounds__(256) void conv_pack_batched_kernel(const unsigned char* __restrict__ jobs, int njobs) {
+  const int bid = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (reinterpret_cast<const PackJob*>(jobs + (size_t)mid * GCA_PACK_JOB_BYTES)->first_block <= bid) lo = mid;
+    else hi = mid - 1;
+  }
+  const PackJob* j = reinterpret_cast<const PackJob*>(jobs + (size_t)lo * GCA_PACK_JOB_BYTES);
+  const PackParams p = j->p;
+  const long long base = (long long)(bid - j->first_block) * PACK_CHUNK;
+  long long end = base + PACK_CHUNK;
+  const long long total = (long long)p.Mrows * p.Kpad;
+  if (end > total) end = total;
+  pack_elements(j->w, j->packed, p, base + threadIdx.x, 256, end);
 }
 
 __global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
@@ -627,20 +660,69 @@ int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   return n > 0 ? n : 64;
 }
 
+static void pack_params_of(const gca_conv_geom* g, int which, const ClassInfo& c, PackParams& p) {
+  const int T = taps(g);
+  p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = (int)c.Kpad; p.Mrows = pack_rows(c.M);
+  p.ntaps = c.ntaps; p.nb = c.nb; p.nc = c.nc;
+  p.k0d = c.k0[0]; p.k0h = c.k0[1]; p.k0w = c.k0[2]; p.sd = c.ks[0]; p.sh = c.ks[1]; p.sw = c.ks[2];
+  p.KH = g->kh; p.KW = g->kw; p.T = T;
+  if (which == 0) { p.s_ch = T; p.s_m = (long long)g->C * T; }       // W[m=ko][ch=c][tap]
+  else { p.s_ch = (long long)g->C * T; p.s_m = T; }                  // W[ch=ko][m=c][tap]
+}
+
+int64_t gca_conv_pack_jobs_host(const gca_conv_geom* g, int which, const float* w, float* packed, void* jobs_out) {
+  if (!geom_ok(g) || (which != 0 && which != 1)) return GCA_EINVAL;
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  int64_t n = 0;
+  for (const ClassInfo& c : cls) {
+    if (c.ntaps == 0) continue;
+    if (jobs_out) {
+      if (!w || !packed) return GCA_EINVAL;
+      PackJob j{};
+      pack_params_of(g, which, c, j.p);
+      j.w = w; j.packed = packed + c.pack_off;
+      j.first_block = 0;
+      j.nblocks = (int)gca_ceil_div((long long)j.p.Mrows * j.p.Kpad, PACK_CHUNK);
+      unsigned char* dst = reinterpret_cast<unsigned char*>(jobs_out) + (size_t)n * GCA_PACK_JOB_BYTES;
+      memset(dst, 0, GCA_PACK_JOB_BYTES);
+      memcpy(dst, &j, sizeof(j));
+    }
+    ++n;
+  }
+  return n;
+}
+
+int64_t gca_conv_pack_jobs_finalize_host(void* jobs, int64_t njobs) {
+  if (!jobs || njobs <= 0) return GCA_EINVAL;
+  int64_t first = 0;
+  for (int64_t i = 0; i < njobs; ++i) {
+    PackJob j;
+    unsigned char* rec = reinterpret_cast<unsigned char*>(jobs) + (size_t)i * GCA_PACK_JOB_BYTES;
+    memcpy(&j, rec, sizeof(j));
+    if (j.nblocks <= 0 || first + j.nblocks > 0x7fffffffLL) return GCA_EINVAL;
+    j.first_block = (int)first;
+    first += j.nblocks;
+    memcpy(rec, &j, sizeof(j));
+  }
+  return first;
+}
+
+int gca_conv_pack_batched(const void* jobs_dev, int64_t njobs, int64_t total_blocks, void* stream) {
+  if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return GCA_EINVAL;
+  hipLaunchKernelGGL(conv_pack_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const unsigned char*>(jobs_dev), (int)njobs);
+  return gca_launch_status();
+}
+
 int gca_conv_pack(const gca_conv_geom* g, int which, const float* w, float* packed, void* stream) {
   if (!geom_ok(g) || (which != 0 && which != 1) || !w || !packed) return GCA_EINVAL;
   std::vector<ClassInfo> cls;
   build_classes(g, which, cls);
-  const int T = taps(g);
   for (const ClassInfo& c : cls) {
     if (c.ntaps == 0) continue;
     PackParams p{};
-    p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = (int)c.Kpad; p.Mrows = pack_rows(c.M);
-    p.ntaps = c.ntaps; p.nb = c.nb; p.nc = c.nc;
-    p.k0d = c.k0[0]; p.k0h = c.k0[1]; p.k0w = c.k0[2]; p.sd = c.ks[0]; p.sh = c.ks[1]; p.sw = c.ks[2];
-    p.KH = g->kh; p.KW = g->kw; p.T = T;
-    if (which == 0) { p.s_ch = T; p.s_m = (long long)g->C * T; }       // W[m=ko][ch=c][tap]
-    else { p.s_ch = (long long)g->C * T; p.s_m = T; }                  // W[ch=ko][m=c][tap]
+    pack_params_of(g, which, c, p);
     long long blocks = gca_ceil_div((long long)p.Mrows * p.Kpad, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,

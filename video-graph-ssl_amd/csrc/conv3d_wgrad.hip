@@ -17,21 +17,9 @@ namespace {
 
 constexpr int LDW = WBK + 4;       // LDS row pitch in floats (144 B)
 
-struct Magic { unsigned m; int s; };        // n / d == (umulhi(n, m) + n') >> s  (Granlund-Montgomery, d >= 1)
-inline Magic make_magic(unsigned d) {
-  Magic g{0, 0};
-  if (d <= 1) return g;                     // handled as identity
-  int s = 0;
-  while ((1ull << s) < d) ++s;
-  g.s = s;
-  g.m = (unsigned)((((1ull << s) - d) << 32) / d + 1);
-  return g;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned d, Magic g) {
-  if (d == 1) return n;
-  const unsigned t = __umulhi(n, g.m);
-  return (t + ((n - t) >> 1)) >> (g.s - 1);
-}
+typedef gca_magic Magic;
+inline Magic make_magic(unsigned d) { return gca_make_magic(d); }
+__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned /*d*/, Magic g) { return gca_fdiv(n, g); }
 
 struct WgradParams {
   int C, D, H, W, K, OD, OH, OW;

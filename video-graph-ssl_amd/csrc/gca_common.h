@@ -14,6 +14,24 @@ static inline int gca_launch_status() {
 static inline int64_t gca_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t gca_round_up(int64_t a, int64_t b) { return gca_ceil_div(a, b) * b; }
 
+// Division of a 31-bit unsigned by a runtime constant without the ~40-instruction integer divide:
+// n / d == (umulhi(n, m) + ((n - umulhi(n, m)) >> 1)) >> (s - 1)   (Granlund-Montgomery round-up method).
+struct gca_magic { unsigned m; int s; unsigned d; };
+static inline gca_magic gca_make_magic(unsigned d) {
+  gca_magic g{0u, 0, d};
+  if (d <= 1) return g;
+  int s = 0;
+  while ((1ull << s) < d) ++s;
+  g.s = s;
+  g.m = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+  return g;
+}
+__device__ __forceinline__ unsigned gca_fdiv(unsigned n, gca_magic g) {
+  if (g.d <= 1) return n;
+  const unsigned t = __umulhi(n, g.m);
+  return (t + ((n - t) >> 1)) >> (g.s - 1);
+}
+
 // XCD-aware block remap (8 XCDs, blocks are dealt round-robin): logical ids that are
 // consecutive end up on the same XCD, so tiles sharing an operand panel share an L2.
 // Bijective for any grid size.  Speed only, never correctness.

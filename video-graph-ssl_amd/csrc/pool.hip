@@ -5,57 +5,103 @@
 
 namespace {
 
-// One thread per output element.  Tie break = first maximum in (d,h,w) scan order and NaN
-// propagates, exactly as ATen's max_pool3d_with_indices (val > max || isnan(val)).
-__global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, const float* __restrict__ x,
+struct PoolMagic {
+  gca_magic osp, ohw, ow;       // output decomposition
+  gca_magic sp, hw, w;          // input decomposition
+  gca_magic sd, sh, sw;         // strides
+};
+
+// One thread per output element.  Tie break = first maximum in (d,h,w) scan order and NaN propagates, exactly
+// as ATen's max_pool3d_with_indices (val > max || isnan(val)).  KD/KH/KW > 0: window fully unrolled with
+// clamped (always in-bounds) loads, so all taps are in flight at once; 0 = run-time window.
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ x,
                                                             float* __restrict__ y, int* __restrict__ argmax,
-                                                            long long total) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                            unsigned total) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int OHW = g.OH * g.OW, OSP = g.OD * OHW;
-  const long long plane = i / OSP;
-  const int o = (int)(i - plane * OSP);
-  const int od = o / OHW, r = o - od * OHW, oh = r / g.OW, ow = r - oh * g.OW;
-  int d0 = od * g.sd - g.pd, h0 = oh * g.sh - g.ph, w0 = ow * g.sw - g.pw;
-  const int d1 = min(d0 + g.kd, g.D), h1 = min(h0 + g.kh, g.H), w1 = min(w0 + g.kw, g.W);
-  d0 = max(d0, 0); h0 = max(h0, 0); w0 = max(w0, 0);
-  const float* xp = x + plane * ((long long)g.D * g.H * g.W);
+  const unsigned plane = gca_fdiv(i, q.osp), o = i - plane * q.osp.d;
+  const int od = (int)gca_fdiv(o, q.ohw), r = (int)(o - (unsigned)od * q.ohw.d);
+  const int oh = (int)gca_fdiv((unsigned)r, q.ow), ow = r - oh * g.OW;
+  const int d0 = od * g.sd - g.pd, h0 = oh * g.sh - g.ph, w0 = ow * g.sw - g.pw;
+  const float* xp = x + (long long)plane * ((long long)g.D * g.H * g.W);
   float best = -INFINITY;
-  int bi = (d0 * g.H + h0) * g.W + w0;
-  for (int d = d0; d < d1; ++d)
-    for (int h = h0; h < h1; ++h)
-      for (int w = w0; w < w1; ++w) {
-        const int idx = (d * g.H + h) * g.W + w;
-        const float v = xp[idx];
-        if (v > best || isnan(v)) { best = v; bi = idx; }
-      }
+  int bi = (max(d0, 0) * g.H + max(h0, 0)) * g.W + max(w0, 0);
+  if (KD > 0) {
+#pragma unroll
+    for (int a = 0; a < KD; ++a)
+#pragma unroll
+      for (int b = 0; b < KH; ++b)
+#pragma unroll
+        for (int c = 0; c < KW; ++c) {
+          const int d = d0 + a, h = h0 + b, w = w0 + c;
+          const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+          const int idx = (d * g.H + h) * g.W + w;
+          const float v = xp[ok ? idx : bi];
+          if (ok && (v > best || isnan(v))) { best = v; bi = idx; }
+        }
+  } else {
+    const int d1 = min(d0 + g.kd, g.D), h1 = min(h0 + g.kh, g.H), w1 = min(w0 + g.kw, g.W);
+    for (int d = max(d0, 0); d < d1; ++d)
+      for (int h = max(h0, 0); h < h1; ++h)
+        for (int w = max(w0, 0); w < w1; ++w) {
+          const int idx = (d * g.H + h) * g.W + w;
+          const float v = xp[idx];
+          if (v > best || isnan(v)) { best = v; bi = idx; }
+        }
+  }
   y[i] = best;
   if (argmax) argmax[i] = bi;
 }
 
-// One thread per INPUT element: gathers from the (few) windows that cover it, no atomics.
-__global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, const float* __restrict__ dy,
+// One thread per INPUT element: gathers from the (few) windows that cover it, no atomics (deterministic, fixed
+// summation order od,oh,ow).  CD/CH/CW = ceil(k/s) per axis is the most windows that can cover one element;
+// > 0: fully unrolled with clamped loads (argmax and dy of all candidates in flight together); 0 = run-time.
+template <int CD, int CH, int CW>
+__global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ dy,
                                                             const int* __restrict__ argmax, float* __restrict__ dx,
-                                                            long long total, int accumulate) {
-  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+                                                            unsigned total, int accumulate) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
-  const int HW = g.H * g.W, SP = g.D * HW;
-  const long long plane = i / SP;
-  const int s = (int)(i - plane * SP);
-  const int d = s / HW, r = s - d * HW, h = r / g.W, w = r - h * g.W;
-  // outputs o with o*s - p <= d < o*s - p + k
-  const int od_lo = max(0, (d + g.pd - g.kd + g.sd) / g.sd), od_hi = min(g.OD - 1, (d + g.pd) / g.sd);
-  const int oh_lo = max(0, (h + g.ph - g.kh + g.sh) / g.sh), oh_hi = min(g.OH - 1, (h + g.ph) / g.sh);
-  const int ow_lo = max(0, (w + g.pw - g.kw + g.sw) / g.sw), ow_hi = min(g.OW - 1, (w + g.pw) / g.sw);
+  const unsigned plane = gca_fdiv(i, q.sp);
+  const int s = (int)(i - plane * q.sp.d);
+  const int d = (int)gca_fdiv((unsigned)s, q.hw), r = s - d * (int)q.hw.d;
+  const int h = (int)gca_fdiv((unsigned)r, q.w), w = r - h * g.W;
+  // outputs o with o*s - p <= v < o*s - p + k   <=>   ceil((v + p - k + 1)/s) <= o <= floor((v + p)/s)
+  const int td = d + g.pd - g.kd + g.sd, th = h + g.ph - g.kh + g.sh, tw = w + g.pw - g.kw + g.sw;
+  const int od_lo = td > 0 ? (int)gca_fdiv((unsigned)td, q.sd) : 0, od_hi = min(g.OD - 1, (int)gca_fdiv((unsigned)(d + g.pd), q.sd));
+  const int oh_lo = th > 0 ? (int)gca_fdiv((unsigned)th, q.sh) : 0, oh_hi = min(g.OH - 1, (int)gca_fdiv((unsigned)(h + g.ph), q.sh));
+  const int ow_lo = tw > 0 ? (int)gca_fdiv((unsigned)tw, q.sw) : 0, ow_hi = min(g.OW - 1, (int)gca_fdiv((unsigned)(w + g.pw), q.sw));
   const int OHW = g.OH * g.OW;
-  const long long obase = plane * ((long long)g.OD * OHW);
+  const long long obase = (long long)plane * ((long long)g.OD * OHW);
   float acc = 0.f;
-  for (int od = od_lo; od <= od_hi; ++od)
-    for (int oh = oh_lo; oh <= oh_hi; ++oh)
-      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-        const long long o = obase + (long long)od * OHW + oh * g.OW + ow;
-        if (argmax[o] == s) acc += dy[o];
-      }
+  if (CD > 0) {
+    constexpr int NE = CD * CH * CW > 0 ? CD * CH * CW : 1;
+    int am[NE];
+    float gv[NE];
+    bool okv[NE];
+#pragma unroll
+    for (int a = 0; a < CD; ++a)
+#pragma unroll
+      for (int b = 0; b < CH; ++b)
+#pragma unroll
+        for (int c = 0; c < CW; ++c) {
+          const int od = od_lo + a, oh = oh_lo + b, ow = ow_lo + c;
+          const bool ok = od <= od_hi && oh <= oh_hi && ow <= ow_hi;
+          const long long o = obase + (ok ? (long long)od * OHW + oh * g.OW + ow : 0);
+          const int e = (a * CH + b) * CW + c;
+          okv[e] = ok; am[e] = argmax[o]; gv[e] = dy[o];
+        }
+#pragma unroll
+    for (int e = 0; e < CD * CH * CW; ++e) acc += (okv[e] && am[e] == s) ? gv[e] : 0.f;
+  } else {
+    for (int od = od_lo; od <= od_hi; ++od)
+      for (int oh = oh_lo; oh <= oh_hi; ++oh)
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+          const long long o = obase + (long long)od * OHW + oh * g.OW + ow;
+          if (argmax[o] == s) acc += dy[o];
+        }
+  }
   dx[i] = accumulate ? dx[i] + acc : acc;
 }
 
@@ -102,11 +148,30 @@ inline bool pool_ok(const gca_pool_geom* g) {
 
 extern "C" {
 
+static PoolMagic pool_magic(const gca_pool_geom* g) {
+  PoolMagic q;
+  q.osp = gca_make_magic((unsigned)(g->OD * g->OH * g->OW)); q.ohw = gca_make_magic((unsigned)(g->OH * g->OW));
+  q.ow = gca_make_magic((unsigned)g->OW);
+  q.sp = gca_make_magic((unsigned)(g->D * g->H * g->W)); q.hw = gca_make_magic((unsigned)(g->H * g->W));
+  q.w = gca_make_magic((unsigned)g->W);
+  q.sd = gca_make_magic((unsigned)g->sd); q.sh = gca_make_magic((unsigned)g->sh); q.sw = gca_make_magic((unsigned)g->sw);
+  return q;
+}
+
 int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, void* stream) {
   if (!pool_ok(g) || !x || !y) return GCA_EINVAL;
   const long long total = (long long)g->N * g->C * g->OD * g->OH * g->OW;
-  hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, *g, x, y, argmax, total);
+  if (total >= (1LL << 31) || (long long)g->D * g->H * g->W >= (1LL << 31)) return GCA_EINVAL;
+  const PoolMagic q = pool_magic(g);
+  const dim3 grid((unsigned)gca_ceil_div(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+#define GCA_POOL_FWD(KD, KH, KW) \
+  hipLaunchKernelGGL((maxpool3d_fwd_kernel<KD, KH, KW>), grid, dim3(256), 0, st, *g, q, x, y, argmax, (unsigned)total)
+  if (g->kd == 3 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(3, 3, 3);
+  else if (g->kd == 1 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(1, 3, 3);
+  else if (g->kd == 2 && g->kh == 2 && g->kw == 2) GCA_POOL_FWD(2, 2, 2);
+  else GCA_POOL_FWD(0, 0, 0);
+#undef GCA_POOL_FWD
   return gca_launch_status();
 }
 
@@ -114,8 +179,20 @@ int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* ar
                       int accumulate, void* stream) {
   if (!pool_ok(g) || !dy || !argmax || !dx) return GCA_EINVAL;
   const long long total = (long long)g->N * g->C * g->D * g->H * g->W;
-  hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, *g, dy, argmax, dx, total, accumulate ? 1 : 0);
+  if (total >= (1LL << 31)) return GCA_EINVAL;
+  const PoolMagic q = pool_magic(g);
+  const dim3 grid((unsigned)gca_ceil_div(total, 256));
+  hipStream_t st = (hipStream_t)stream;
+  const int cd = (int)gca_ceil_div(g->kd, g->sd), ch = (int)gca_ceil_div(g->kh, g->sh), cw = (int)gca_ceil_div(g->kw, g->sw);
+#define GCA_POOL_BWD(CD, CH, CW) \
+  hipLaunchKernelGGL((maxpool3d_bwd_kernel<CD, CH, CW>), grid, dim3(256), 0, st, *g, q, dy, argmax, dx, (unsigned)total, \
+                     accumulate ? 1 : 0)
+  if (cd == 2 && ch == 2 && cw == 2) GCA_POOL_BWD(2, 2, 2);
+  else if (cd == 1 && ch == 2 && cw == 2) GCA_POOL_BWD(1, 2, 2);
+  else if (cd == 3 && ch == 3 && cw == 3) GCA_POOL_BWD(3, 3, 3);
+  else if (cd == 1 && ch == 1 && cw == 1) GCA_POOL_BWD(1, 1, 1);
+  else GCA_POOL_BWD(0, 0, 0);
+#undef GCA_POOL_BWD
   return gca_launch_status();
 }
 

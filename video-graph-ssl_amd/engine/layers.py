@@ -21,7 +21,70 @@ def _grad_of(p):
 
 
 # ----------------------------------------------------------------------------- leaf modules
-class HipConv3d(nn.Module):
+class _PackedWeight(object):
+    """Weights are consumed in the MFMA-friendly packed layout (gca_conv_pack).  A layer packs on use, unless a
+    BatchedPacker has already refreshed this step's copy for the same plan (one launch for the whole encoder)."""
+
+    def _init_pack(self):
+        self._pack, self._pack_plan, self._prepacked = [None, None], [None, None], [False, False]
+
+    def packed(self, plan, which):
+        if self._prepacked[which] and self._pack_plan[which] is plan:
+            return self._pack[which]
+        self._pack[which] = ops.conv_pack(plan, which, self.weight.data, self._pack[which])
+        self._pack_plan[which] = plan
+        return self._pack[which]
+
+
+class BatchedPacker(object):
+    """One gca_conv_pack_batched launch for every (layer, direction) of `module` that has been used at least
+    once (so its plan and packed buffer exist).  run() at the start of a step, release() at its end."""
+
+    def __init__(self, module, directions):
+        import ctypes
+        H = ops.H
+        recs, self.layers = [], []
+        dev = None
+        for m in module.modules():
+            if not isinstance(m, _PackedWeight):
+                continue
+            for which in directions:
+                plan, buf = m._pack_plan[which], m._pack[which]
+                if plan is None or buf is None:
+                    continue
+                n = H.lib.gca_conv_pack_jobs_host(plan.gp, which, None, None, None)
+                if n <= 0:
+                    raise RuntimeError('gca_conv_pack_jobs_host: %d' % n)
+                raw = ctypes.create_string_buffer(int(n) * H.PACK_JOB_BYTES)
+                if H.lib.gca_conv_pack_jobs_host(plan.gp, which, m.weight.data_ptr(), buf.data_ptr(), raw) != n:
+                    raise RuntimeError('gca_conv_pack_jobs_host failed')
+                recs.append(raw.raw)
+                self.layers.append((m, which, plan, buf))
+                dev = buf.device
+        blob = ctypes.create_string_buffer(b''.join(recs))
+        self.n = (len(blob) - 1) // H.PACK_JOB_BYTES
+        self.jobs, self.blocks = None, 0
+        if self.n:
+            self.blocks = H.lib.gca_conv_pack_jobs_finalize_host(blob, self.n)
+            if self.blocks <= 0:
+                raise RuntimeError('gca_conv_pack_jobs_finalize_host: %d' % self.blocks)
+            self.jobs = torch.frombuffer(bytearray(blob.raw[:self.n * H.PACK_JOB_BYTES]), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        if not self.n:
+            return
+        for m, which, plan, buf in self.layers:
+            if m._pack[which] is not buf or m._pack_plan[which] is not plan:
+                raise RuntimeError('BatchedPacker is stale (a layer was re-planned); rebuild it')
+            m._prepacked[which] = True
+        ops.H.call('gca_conv_pack_batched', ops.ptr(self.jobs), self.n, self.blocks, ops.stream())
+
+    def release(self):
+        for m, which, _, _ in self.layers:
+            m._prepacked[which] = False
+
+
+class HipConv3d(nn.Module, _PackedWeight):
     """nn.Conv3d(bias=False|True) parameters; default init = torch's (kaiming_uniform a=sqrt 5)."""
 
     def __init__(self, cin, cout, kernel_size, stride=1, padding=0, bias=False):
@@ -35,7 +98,7 @@ class HipConv3d(nn.Module):
         if bias:
             bound = 1 / math.sqrt(cin * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2])
             nn.init.uniform_(self.bias, -bound, bound)
-        self._pack = [None, None]
+        self._init_pack()
 
     def plan(self, x):
         xs = 0
@@ -46,10 +109,6 @@ class HipConv3d(nn.Module):
             xs = x.stride(0)
         return ops.conv_plan(tuple(x.shape), self.out_channels, self.kernel_size, self.stride, self.padding,
                              x.device, xs)
-
-    def packed(self, plan, which):
-        self._pack[which] = ops.conv_pack(plan, which, self.weight.data, self._pack[which])
-        return self._pack[which]
 
     def forward(self, x):      # plain inference use of the leaf (no BN fusion)
         return ops.conv_fwd(self.plan(x), x, self.packed(self.plan(x), 0), None if self.bias is None else self.bias.data)
@@ -74,7 +133,7 @@ class HipBatchNorm1d(_HipBatchNorm):
     pass
 
 
-class HipLinear(nn.Module):
+class HipLinear(nn.Module, _PackedWeight):
     def __init__(self, fin, fout, bias=True):
         super().__init__()
         self.in_features, self.out_features = fin, fout
@@ -84,14 +143,10 @@ class HipLinear(nn.Module):
         if bias:
             bound = 1 / math.sqrt(fin)
             nn.init.uniform_(self.bias, -bound, bound)
-        self._pack = [None, None]
+        self._init_pack()
 
     def plan(self, b, device):
         return ops.conv_plan((b, self.in_features, 1, 1, 1), self.out_features, 1, 1, 0, device)
-
-    def packed(self, plan, which):
-        self._pack[which] = ops.conv_pack(plan, which, self.weight.data, self._pack[which])
-        return self._pack[which]
 
 
 class HipMaxPool3d(nn.Module):

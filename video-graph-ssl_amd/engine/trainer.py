@@ -16,6 +16,7 @@ import torch
 
 from . import ops
 from .arena import arena_of
+from .layers import BatchedPacker
 from .tape import Tape, Var
 from .. import parallel as par
 from ..lib.memory import create_contrast, create_criterion
@@ -82,6 +83,7 @@ class MoCoTrainer(object):
         self.perm_seed = int(getattr(cfg.MODEL, 'SEED', 1))
         self._static = None
         self._segments = None
+        self._packers = None        # built after the first (eager) step, when every layer has its plan
         self.out = {}
 
     # -------------------------------------------------------------------------------- buffers
@@ -99,20 +101,33 @@ class MoCoTrainer(object):
                 all_k=torch.empty((b * W, D), dtype=torch.float32, device=self.device),
                 enq_idx=torch.empty(b, dtype=torch.long, device=self.device))
             self._segments = None
+            self._packers = None
         return self._static
+
+    def _pack(self, which):
+        """Refresh the packed weights of a whole encoder in one launch (layers skip their own packing)."""
+        if self._packers is not None:
+            self._packers[which].run()
+
+    def _unpack(self, which):
+        if self._packers is not None:
+            self._packers[which].release()
 
     # -------------------------------------------------------------------------------- phases
     def _phase_key(self):
         """k (shuffled order on N>1) = key_encoder(key_in); no tape, BN train mode."""
         s = self._static
         x2 = s['key_in'] if self.ctx.active else torch.chunk(s['images'], 2, dim=1)[1]
+        self._pack('k')
         kv = self.model_ema.fwd(Tape(False), Var(x2))
+        self._unpack('k')
         s['k_shuf'].copy_(kv.t)
 
     def _phase_query(self):
         s = self._static
         b = s['images'].shape[0]
         self.optimizer.zero_grad()
+        self._pack('q')
         tape = Tape(True)
         qv = self.model.fwd(tape, Var(torch.chunk(s['images'], 2, dim=1)[0]))
         mem = self.contrast.memory
@@ -124,6 +139,7 @@ class MoCoTrainer(object):
                                       gscale_host=1.0 / self.ctx.world, ov_rows=saved, ov_start_dev=self.ptr_dev)
         ops.queue_advance(self.ptr_dev, s['all_k'].shape[0], self.K)
         tape.backward()
+        self._unpack('q')
         self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
 
     def _phase_update(self):
@@ -169,6 +185,8 @@ class MoCoTrainer(object):
             self._segments[1].run()
             par.allreduce_sum_(self.arena_q.grad, self.ctx)
             self._segments[2].run()
+        if self._packers is None:
+            self._packers = dict(k=BatchedPacker(self.model_ema, (0,)), q=BatchedPacker(self.model, (0, 1)))
         self.contrast.index = (self.contrast.index + b * W) % self.K      # host mirror of ptr_dev
         self.step_count += 1
         return self.out
@@ -196,18 +214,23 @@ class SimSiamTrainer(object):
         self.scheduler = make_lr_scheduler(cfg, self.optimizer)
         self.model.train()
         self.use_graph = bool(use_graph)
-        self._static, self._segments, self.out = None, None, {}
+        self._static, self._segments, self._packer, self.out = None, None, None, {}
 
     def _fwd_bwd(self):
         self.optimizer.zero_grad()
+        if self._packer is not None:
+            self._packer.run()
         tape = Tape(True)
         lv = self.model.fwd(tape, Var(self._static))
         tape.backward()
+        if self._packer is not None:
+            self._packer.release()
         self.out = dict(loss=lv.t)
 
     def train_step(self, images):
         if self._static is None or self._static.shape != images.shape:
             self._static = torch.empty_like(images)
+            self._packer = None
             self._segments = [_Graphed(self._fwd_bwd, self.use_graph), _Graphed(self.optimizer.step, self.use_graph)]
         self._static.copy_(images)
         self.optimizer._sync_tables()
@@ -216,4 +239,6 @@ class SimSiamTrainer(object):
             par.allreduce_sum_(self.arena.grad, self.ctx)
             ops.scale_(self.arena.grad, 1.0 / self.ctx.world)
         self._segments[1].run()
+        if self._packer is None:
+            self._packer = BatchedPacker(self.model, (0, 1))
         return self.out
