@@ -110,9 +110,9 @@ def _bm(dk):
 
 
 def _sym(c):
-    """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<9}."""
-    vec, fast = (c[3] >> 9) & 1, (c[3] >> 8) & 1
-    return 'conv_igemm_kernel<%d,%d,%s,%s>' % (c[0] // 32, c[1], 'true' if fast else 'false', 'true' if vec else 'false')
+    """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10}."""
+    vec, fast = (c[3] >> 10) & 1, (c[3] >> 8) & 3
+    return 'conv_igemm_kernel<%d,%d,%d,%s>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false')
 
 
 def kernel_timing(pkg, trainer, args):

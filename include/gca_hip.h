@@ -88,7 +88,7 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_
  * layout [K][P], P = gca_conv_fwd_stat_parts(g). */
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
 /* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad), first non-empty class:
- * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask<<8 | float4-gather<<9}. */
+ * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask kind (0 none, 1: <=31 taps, 2: <=62)<<8 | float4-gather<<10}. */
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
 /* Layers whose output grid cannot fill the 256 CUs split the reduction over workgroups; the fp32
  * partial slabs live in `ws` (gca_conv_fwd_ws_bytes / gca_conv_dgrad_ws_bytes; 0 = not needed, ws may

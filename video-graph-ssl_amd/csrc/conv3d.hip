@@ -55,6 +55,7 @@ struct IgemmParams {
   long long Ntot;
   long long src_nstride;   // elements between consecutive images of the gathered tensor
   unsigned src_bytes;      // extent of the gathered tensor for the buffer resource (range check)
+  unsigned dst_bytes;      // extent of the destination tensor
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -64,12 +65,13 @@ struct IgemmParams {
 // k-tile of 16 is 2 reads per operand tile followed by an uninterrupted chain of 8*TM*TN MFMAs.  (A lane of
 // half h holds k = 8t + 4h + e of its row; MFMA step (t, e) therefore sums k = 8t+e and 8t+4+e -- the same
 // permutation on both operands.)
-// FAST: tap-mask path (class has <= 62 taps).  VEC: float4 gathers (BN = 256, every lane owns 4
-// consecutive columns, a wave covers one whole tile row per load).
+// FAST: 1 = tap-mask path with <= 31 taps (one v_bfe_i32 per gathered element), 2 = <= 62 taps, 0 = window
+// tests per element (huge kernels, e.g. 7x7x7).  VEC: float4 gathers (BN = 256, every lane owns 4 consecutive
+// columns, a wave covers one whole tile row per load).
 // ---------------------------------------------------------------------------------------------
 constexpr int LDK = BK + 4;     // LDS row pitch in floats (80 B)
 
-template <int TM, int BN, bool FAST, bool VEC>
+template <int TM, int BN, int FAST, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   constexpr int BM = 32 * TM, TN = BN / 128, WN = 4;
   constexpr int A_F4 = (BM * 4 + 255) / 256;               // float4 loads per thread for the A tile (BM x 16)
   constexpr int B_PER = VEC ? 4 : 8;                       // gathers per thread for the B tile
-  static_assert(!VEC || (BN == 256 && FAST), "VEC variant: 256 columns, tap-mask path");
+  static_assert(!VEC || (BN == 256 && FAST == 1), "VEC variant: 256 columns, <= 32-tap mask path");
   static_assert(BN == 128 || BN == 256, "BN");
 
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   if (FAST) {
     for (int t = 0; t < p.ntaps; ++t) {
       const int pk = taptab[t];
-      const int dd = (pk << 24) >> 24, dh = (pk << 16) >> 24, dw = (pk << 8) >> 24;
+      const int dd = (pk << 16) >> 24, dh = (pk << 8) >> 24, dw = pk >> 24;
       bool ok = cvalid;
       if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.SD);
       if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
@@ -135,16 +137,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 
   float breg[VEC ? 1 : B_PER];
   float4 bvec[VEC ? B_PER : 1];
-  float4 areg[A_F4];
+  // A tile (BM x 16 packed weights, k contiguous): up to three float4 slots per thread, kept in named scalars
+  // (an indexed array with a predicated tail makes the compiler park it in scratch).  The tail slot is loaded
+  // unconditionally from a clamped index and only its LDS store is predicated.
+  static_assert(A_F4 <= 3, "A tile slots");
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
   const float* arow = apack + (long long)tileM * BM * p.Kpad;      // packed weights [Mpad][Kpad], k contiguous
+  constexpr bool A_TAIL = (BM * 4) % 256 != 0;                      // last slot only partly populated
+  const bool a_last_ok = !A_TAIL || tid + (A_F4 - 1) * 256 < BM * 4;
+  auto a_slot = [&](int i) __attribute__((always_inline)) {
+    int idx = tid + i * 256;
+    if (A_TAIL && idx >= BM * 4) idx = BM * 4 - 1;
+    return idx;
+  };
+  const int ao0 = (a_slot(0) >> 2) * p.Kpad + (a_slot(0) & 3) * 4;
+  const int ao1 = A_F4 > 1 ? (a_slot(1) >> 2) * p.Kpad + (a_slot(1) & 3) * 4 : 0;
+  const int ao2 = A_F4 > 2 ? (a_slot(2) >> 2) * p.Kpad + (a_slot(2) & 3) * 4 : 0;
 
-  auto load_tiles = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * 256;
-      if ((BM * 4) % 256 == 0 || idx < BM * 4)
-        areg[i] = *reinterpret_cast<const float4*>(arow + (long long)(idx >> 2) * p.Kpad + kt * BK + (idx & 3) * 4);
-    }
+  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+    a0 = *reinterpret_cast<const float4*>(arow + ao0 + kt * BK);
+    if (A_F4 > 1) a1 = *reinterpret_cast<const float4*>(arow + ao1 + kt * BK);
+    if (A_F4 > 2) a2 = *reinterpret_cast<const float4*>(arow + ao2 + kt * BK);
     // B: gathered window.  Rows are uniform across the wave: fetch their table entries first (scalar,
     // one batch), then issue all gathers back to back.
     const int2* trow = table + kt * BK + __builtin_amdgcn_readfirstlane(r0);
@@ -155,10 +168,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       int inv;                                            // 0 = valid, -1 = invalid
-      if (FAST) {
-        const int tap6 = (e[i].y >> 25) & 63;
-        const unsigned m = tap6 < 32 ? ilo : ihi;
-        inv = (int)(m << (31 - (tap6 & 31))) >> 31;
+      if (FAST == 1) {
+        inv = __builtin_amdgcn_sbfe((int)ilo, e[i].y, 1);            // bit (y & 31) of the mask, sign extended
+      } else if (FAST == 2) {
+        const unsigned m = (e[i].y & 32) ? ihi : ilo;
+        inv = __builtin_amdgcn_sbfe((int)m, e[i].y, 1);
       } else {
         int off, dd, dh, dw, rvalid;
         decode_row(e[i], off, dd, dh, dw, rvalid);
@@ -183,13 +197,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
       for (int i = 0; i < B_PER; ++i) breg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[i], 0, 0));
     }
   };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_F4; ++i) {
-      const int idx = tid + i * 256;
-      if ((BM * 4) % 256 == 0 || idx < BM * 4)
-        *reinterpret_cast<float4*>(&As[buf][idx >> 2][(idx & 3) * 4]) = areg[i];
-    }
+  auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    if (A_F4 > 1 || a_last_ok) *reinterpret_cast<float4*>(&As[buf][a_slot(0) >> 2][(a_slot(0) & 3) * 4]) = a0;
+    if (A_F4 == 2 ? a_last_ok : A_F4 > 2) *reinterpret_cast<float4*>(&As[buf][a_slot(1) >> 2][(a_slot(1) & 3) * 4]) = a1;
+    if (A_F4 > 2 && a_last_ok) *reinterpret_cast<float4*>(&As[buf][a_slot(2) >> 2][(a_slot(2) & 3) * 4]) = a2;
     if (VEC) {      // 4 k-rows x 4 columns per thread: transpose in registers, one b128 per column
       *reinterpret_cast<float4*>(&Bs[buf][col + 0][r0]) = make_float4(bvec[0].x, bvec[1].x, bvec[2].x, bvec[3].x);
       *reinterpret_cast<float4*>(&Bs[buf][col + 1][r0]) = make_float4(bvec[0].y, bvec[1].y, bvec[2].y, bvec[3].y);
@@ -242,28 +253,37 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Stores go through a buffer resource: the lane keeps ONE 32-bit byte offset per column tile (its column and
+  // its row half), the row part of the address is wave-uniform (soffset), and an invalid row or column is an
+  // all-ones offset that the hardware drops -- the epilogue needs a handful of VGPRs instead of 16 pointers.
   const int mbase = tileM * BM;
+  const int rows_left = p.DK - mbase - 4 * lh;              // row (i,r) of this lane is real iff i*32 + ro(r) < rows_left
   if (p.splits > 1) {
     // partial tile -> slab[split][m][n]; bias / accumulate / BN sums happen in conv_splitk_finish_kernel
     float* sl = slab + (long long)split * p.DK * p.Ntot;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(sl, 0, p.dst_bytes, 0x00020000);
+    const unsigned rowb = (unsigned)p.Ntot * 4u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const long long n = (long long)tileN * BN + wn * (TN * 32) + j * 32 + ll;
-      if (n < p.Ntot) {
+      const unsigned vb = n < p.Ntot ? ((unsigned)n + (unsigned)(mbase + 4 * lh) * (unsigned)p.Ntot) * 4u : 0xffffffffu;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m < p.DK) sl[(long long)m * p.Ntot + n] = acc[i][j][r];
-          }
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+          const unsigned vo = ro < rows_left ? vb : 0xffffffffu;
+          const float v = acc[i][j][r];     // NB: never bit_cast a vector ELEMENT expression (hipcc 7.2 takes element 0)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)ro * rowb), 0);
+        }
     }
     return;
   }
   const int DHW = p.DH * p.DW;
-  const long long DSP = (long long)p.DD * DHW;
+  const unsigned DSP = (unsigned)(p.DD * DHW);
+  const unsigned rowb = DSP * 4u;
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, p.dst_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const long long n = (long long)tileN * BN + wn * (TN * 32) + j * 32 + ll;
@@ -273,32 +293,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const int sp = (int)(nc - (long long)img * QSP);
     const int qd = sp / QHW, rr = sp - qd * QHW;
     const int qh = rr / p.QW, qw = rr - qh * p.QW;
-    const long long dsp = (long long)(qd * p.dm_d + p.do_d) * DHW + (qh * p.dm_h + p.do_h) * p.DW + (qw * p.dm_w + p.do_w);
-    float* d0 = dst + ((long long)img * p.DK) * DSP + dsp;
+    const unsigned dsp = (unsigned)((qd * p.dm_d + p.do_d) * DHW + (qh * p.dm_h + p.do_h) * p.DW + (qw * p.dm_w + p.do_w));
+    const unsigned vb = nv ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * 4u : 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float old[16];
       if (p.accumulate) {                       // all 16 read-modify-write loads in flight together
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          old[r] = (nv && m < p.DK) ? d0[(long long)m * DSP] : 0.f;
+          const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+          const unsigned vo = ro < rows_left ? vb : 0xffffffffu;
+          old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (int)vo, (int)((unsigned)ro * rowb), 0));
         }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (nv && m < p.DK) {
-          float v = acc[i][j][r];
-          if (bias) v += bias[m];
-          if (p.accumulate) v += old[r];
-          d0[(long long)m * DSP] = v;
-        }
+        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+        const unsigned vo = ro < rows_left ? vb : 0xffffffffu;
+        float v = acc[i][j][r];
+        if (bias) v += bias[min(mbase + ro + 4 * lh, p.DK - 1)];
+        if (p.accumulate) v += old[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)ro * rowb), 0);
       }
     }
   }
   if (psum) {
-    // per-channel partial sum / sum of squares over this wave's columns (invalid columns hold 0)
+    // per-channel partial sum / sum of squares over this wave's columns (invalid columns hold 0): DPP adds over
+    // the 32 lanes of each wave half; the totals land in lanes 16..31 / 48..63.
     const int part = tileN * WN + wn;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -307,12 +328,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int j = 0; j < TN; ++j) { const float v = acc[i][j][r]; s += v; q += v * v; }
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-        const int m = mbase + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ll == 0 && m < p.DK) {
-          psum[(long long)m * p.P + part] = s;
-          psq[(long long)m * p.P + part] = q;
+        s = half_wave_sum_hi(s);
+        q = half_wave_sum_hi(q);
+        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+        if (ll == 31 && ro < rows_left) {
+          const long long m = mbase + ro + 4 * lh;
+          psum[m * p.P + part] = s;
+          psq[m * p.P + part] = q;
         }
       }
     }
@@ -432,6 +454,7 @@ struct ClassInfo {
 };
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int fast_of(int ntaps) { return ntaps <= 31 ? 1 : (ntaps <= FAST_MAX_TAPS ? 2 : 0); }
 inline int pack_rows(int M);
 
 // which: 0 forward, 1 dgrad
@@ -450,7 +473,7 @@ void build_classes(const gca_conv_geom* g, int which, std::vector<ClassInfo>& ou
     const int SH = which == 0 ? in[1] : od[1], SW = which == 0 ? in[2] : od[2];
     c.vec = c.nb == 1 && c.nc == 1 && c.m[1] == 1 && c.m[2] == 1 && c.o[1] + c.dl0[1] == 0 && c.o[2] + c.dl0[2] == 0 &&
             c.dm[1] == 1 && c.dm[2] == 1 && c.dof[1] == 0 && c.dof[2] == 0 && c.q[1] == SH && c.q[2] == SW &&
-            (SH * SW) % 4 == 0 && c.ntaps <= FAST_MAX_TAPS &&
+            (SH * SW) % 4 == 0 && c.ntaps <= 31 &&
             (which == 1 || g->x_batch_stride % 4 == 0);
     out.push_back(c);
   };
@@ -508,6 +531,8 @@ inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, 
   {
     const long long span = (long long)g->N * p.src_nstride * 4;
     p.src_bytes = span > 0xfffff000LL ? 0xfffff000u : (unsigned)span;
+    const long long dspan = (long long)g->N * p.DK * p.DD * p.DH * p.DW * 4;     // destination tensor (or one slab)
+    p.dst_bytes = dspan > 0xfffff000LL ? 0xfffff000u : (unsigned)dspan;
   }
   // bounds tests: skip a dimension when every tap of every column stays inside by construction
   const int lim[3] = {p.SD, p.SH, p.SW};
@@ -581,7 +606,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
   return choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
 }
 
-template <int TM, int BN, bool FAST, bool VEC>
+template <int TM, int BN, int FAST, bool VEC>
 void launch_one(dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
                 float* dst, float* psum, float* psq, float* slab, const IgemmParams& p) {
   hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC>), grid, dim3(256), 0, st, src, apack, table, bias,
@@ -589,12 +614,13 @@ void launch_one(dim3 grid, hipStream_t st, const float* src, const float* apack,
 }
 
 template <int TM>
-void launch_tm(const IgemmCfg& c, bool fast, dim3 grid, hipStream_t st, const float* src, const float* apack,
+void launch_tm(const IgemmCfg& c, int fast, dim3 grid, hipStream_t st, const float* src, const float* apack,
                const int2* table, const float* bias, float* dst, float* psum, float* psq, float* slab,
                const IgemmParams& p) {
-  if (c.bn == 256) launch_one<TM, 256, true, true>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else if (fast) launch_one<TM, 128, true, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else launch_one<TM, 128, false, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  if (c.bn == 256) launch_one<TM, 256, 1, true>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else if (fast == 1) launch_one<TM, 128, 1, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else if (fast == 2) launch_one<TM, 128, 2, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else launch_one<TM, 128, 0, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
 }
 
 inline int stat_parts(const IgemmCfg& c, long long Ntot) {
@@ -602,7 +628,7 @@ inline int stat_parts(const IgemmCfg& c, long long Ntot) {
   return (int)gca_ceil_div(Ntot, c.bn) * 4;
 }
 
-int run_class(const IgemmCfg& c, bool fast, const float* src, const float* apack, const int2* table, const float* bias,
+int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack, const int2* table, const float* bias,
               float* dst, float* psum, float* psq, float* slab, IgemmParams p, hipStream_t st) {
   p.tilesM = (int)gca_ceil_div(p.DK, c.bm);
   p.tilesN = (int)gca_ceil_div(p.Ntot, c.bn);
@@ -649,7 +675,7 @@ int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
 
 extern "C" {
 
-int gca_version(void) { return 3; }
+int gca_version(void) { return 4; }
 
 int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return GCA_EINVAL;
@@ -800,7 +826,7 @@ int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
     IgemmParams p{};
     class_params(g, which, c, p);
     const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | ((c.ntaps <= FAST_MAX_TAPS) << 8) | (c.vec << 9);
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10);
     return GCA_OK;
   }
   return GCA_EINVAL;
@@ -828,7 +854,7 @@ int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, con
   IgemmParams p{};
   class_params(g, 0, c, p);
   p.accumulate = 0;
-  return run_class(cfg_for(g, 0, c, p, 1), c.ntaps <= FAST_MAX_TAPS, x, wpack, reinterpret_cast<const int2*>(table), bias,
+  return run_class(cfg_for(g, 0, c, p, 1), fast_of(c.ntaps), x, wpack, reinterpret_cast<const int2*>(table), bias,
                    y, stat_sum, stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
 }
 
@@ -853,7 +879,7 @@ int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, 
     IgemmParams p{};
     class_params(g, 1, c, p);
     p.accumulate = accumulate ? 1 : 0;
-    int rc = run_class(cfg_for(g, 1, c, p, cls.size()), c.ntaps <= FAST_MAX_TAPS, dy, wpack + c.pack_off,
+    int rc = run_class(cfg_for(g, 1, c, p, cls.size()), fast_of(c.ntaps), dy, wpack + c.pack_off,
                        tab + c.table_off, nullptr, dx, nullptr, nullptr, reinterpret_cast<float*>(ws), p, st);
     if (rc) return rc;
   }

@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   float4 avec[AVEC ? A_PER : 1];
   float breg[B_PER];
 
-  auto load_tiles = [&](int kt) {
+  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
     // ---- A: dY[img, m, o]
     if (AVEC) {
       const unsigned kp = (unsigned)kt * WBK + kq * 4;          // 4 consecutive positions, same image (OSP % 4 == 0)
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](int buf) __attribute__((always_inline)) {
     if (AVEC) {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) *reinterpret_cast<float4*>(&As[buf][ga + 32 * i][kq * 4]) = avec[i];

@@ -14,16 +14,31 @@ constexpr int TABLE_PAD_W = 128;
 constexpr int FAST_MAX_TAPS = 62;
 constexpr int NUM_CU = 256;
 
-// row table entry: x = element offset; y = dd | dh<<8 | dw<<16 (signed bytes) | valid<<24 | tap6<<25
+// row table entry: x = offset of the row's (channel, tap) inside one image of the gathered tensor (BYTES for the
+// forward/dgrad tables, elements for the wgrad table); y = tap6 | valid<<6 | dd<<8 | dh<<16 | dw<<24 (signed
+// bytes).  The tap id sits in the low bits so that v_bfe_i32(mask, y, 1) tests its validity bit directly.
 __device__ __forceinline__ void decode_row(int2 e, int& off, int& dd, int& dh, int& dw, int& valid) {
   off = e.x;
-  dd = (e.y << 24) >> 24;
-  dh = (e.y << 16) >> 24;
-  dw = (e.y << 8) >> 24;
-  valid = (e.y >> 24) & 1;
+  dd = (e.y << 16) >> 24;
+  dh = (e.y << 8) >> 24;
+  dw = e.y >> 24;
+  valid = (e.y >> 6) & 1;
 }
 inline int pack_row_meta(int dd, int dh, int dw, int valid, int tap6) {
-  return (dd & 0xff) | ((dh & 0xff) << 8) | ((dw & 0xff) << 16) | ((valid & 1) << 24) | ((tap6 & 63) << 25);
+  return (tap6 & 63) | ((valid & 1) << 6) | ((dd & 0xff) << 8) | ((dh & 0xff) << 16) | (int)((unsigned)(dw & 0xff) << 24);
+}
+
+// Sum over the 32 lanes of each wave half with DPP adds (no LDS traffic).  The total lands in lanes 16..31 of
+// the lower half and 48..63 of the upper half (row_bcast15 feeds rows 1 and 3).
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+#define GCA_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
+  v += GCA_DPP(v, 0xB1, 0xf);     // quad_perm [1,0,3,2]
+  v += GCA_DPP(v, 0x4E, 0xf);     // quad_perm [2,3,0,1]
+  v += GCA_DPP(v, 0x141, 0xf);    // row_half_mirror
+  v += GCA_DPP(v, 0x140, 0xf);    // row_mirror   -> every lane of a 16-lane row holds the row total
+  v += GCA_DPP(v, 0x142, 0xa);    // row_bcast15 into rows 1 and 3
+#undef GCA_DPP
+  return v;
 }
 
 inline bool geom_ok(const gca_conv_geom* g) {
