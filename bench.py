@@ -101,14 +101,6 @@ def conv_layers_of(model, x_shape, pkg):
     return out
 
 
-def _bm(dk):
-    """Mirror of the wgrad tile rule in csrc/conv3d.hip (wgrad_plan): tile edge picked for `dk` GEMM rows/cols."""
-    if dk <= 64:
-        return 64
-    t128, t64 = -(-dk // 128) * 128, -(-dk // 64) * 64
-    return 64 if ((t128 - dk) * 4 > t128 and t64 < t128) else 128
-
-
 def _sym(c):
     """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10}."""
     vec, fast = (c[3] >> 10) & 1, (c[3] >> 8) & 3
@@ -150,11 +142,12 @@ def kernel_timing(pkg, trainer, args):
             c1 = plan.cfg(1)
             add(_sym(c1), t, flops, 1)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
-        add('conv_wgrad_kernel<%d,%d>' % (_bm(K), _bm(shp[1] * taps)), t, flops, 1)
+        cw = plan.cfg(2)
+        add('conv_wgrad_kernel<%dx%d>' % (cw[0], cw[1]), t, flops, 1)
         if args.layer_table:
-            log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
+            log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%s/%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
                 % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, plan.cfg(0)[:3], plan.cfg(1)[:3] if i > 0 else '-',
-                   plan.g.tune_wgrad_splits, t_f, flops / 1e9 / t_f,
+                   '%dx%d' % plan.cfg(2)[:2], plan.cfg(2)[2], t_f, flops / 1e9 / t_f,
                    ('%7.3f ms %6.1f TF' % (t_d, flops / 1e9 / t_d)) if t_d else '      --       ', t, flops / 1e9 / t))
         del x, dy, dx
     table = {k: dict(ms_per_step=round(v[0], 4), gflop_per_step=round(v[1] / 1e9, 2), launches_per_step=v[2],

@@ -55,7 +55,7 @@ typedef struct {
   int32_t tune_fwd_bm, tune_fwd_splits;       /* tile rows 32..160 (x128 columns), | 1024 = x256 columns with float4
                                                  gathers (pointwise-in-space convs only); split-K factor */
   int32_t tune_dgrad_bm, tune_dgrad_splits;
-  int32_t tune_wgrad_splits, tune_reserved;
+  int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile shape index 1..10 (see gca_conv_wgrad_cfg), 0 = heuristic */
 } gca_conv_geom;
 
 /* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward
@@ -107,6 +107,9 @@ int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, 
 int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g);
 int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream);
+/* Launch shape the wgrad kernel will use for g: out4 = {tile rows (output channels), tile columns (C*taps),
+ * split-K factor, shape index | float4 dY loads<<8 | tap-mask kind<<9}. */
+int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4);
 
 /* db[k] (+)= sum over (n, spatial) of dy[n,k,:]   (bias gradient of the nn.Linear layers) */
 int gca_bias_grad(const float* dy, int64_t N, int64_t K, int64_t SP, float* db, int accumulate, void* stream);

@@ -102,6 +102,40 @@ def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
             assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4
             assert rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-4
     assert len(seen) >= 8
+    # every wgrad tile shape (1..10; shapes not built for this tap count fall back to the heuristic one)
+    seen_w = set()
+    for idx in range(1, 11):
+        for sp in (1, 5):
+            plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = idx, sp
+            plan.refresh()
+            seen_w.add(plan.cfg(2)[:2])
+            dw = torch.zeros_like(wd)
+            ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
+            assert rel_err(dw, wr.grad) < 1e-5, (idx, sp, plan.cfg(2))
+    assert len(seen_w) >= 6
+
+
+@pytest.mark.parametrize('shape,K,k,s,p', [
+    ((2, 3, 2, 20, 20), 40, (1, 7, 7), (1, 2, 2), (0, 3, 3)),       # 49 taps: 64-bit tap mask (the R(2+1)D stem)
+    ((1, 2, 9, 9, 9), 5, (7, 7, 7), (1, 2, 2), (3, 3, 3)),          # 343 taps: per-element window tests (3D-ResNet stem)
+    ((2, 6, 5, 7, 7), 10, (3, 3, 3), (1, 1, 1), (1, 1, 1)),         # 27 taps, all three axes padded
+])
+def test_conv_wgrad_tap_mask_kinds(ops, shape, K, k, s, p):
+    torch.manual_seed(3)
+    x = torch.randn(shape)
+    w = torch.randn((K, shape[1]) + tuple(k)) * 0.1
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv3d(x, wr, None, s, p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    plan = ops.ConvPlan(*shape, K, k, s, p, DEV)
+    plan.tuned = [True, True, True]
+    for idx in range(0, 11):
+        plan.g.tune_wgrad_tile = idx
+        plan.refresh()
+        dw = torch.zeros_like(w).to(DEV)
+        ops.conv_wgrad(plan, x.to(DEV), dy.to(DEV), dw, accumulate=True)
+        assert rel_err(dw, wr.grad) < 1e-5, (idx, plan.cfg(2))
 
 
 def test_conv_batch_stride_views(ops):

@@ -24,7 +24,7 @@ def test_abi_exports_every_declared_symbol(pkg):
     assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
     for name in declared:
         assert getattr(pkg._hip.lib, name) is not None
-    assert pkg._hip.lib.gca_version() >= 3
+    assert pkg._hip.lib.gca_version() >= 4
 
 
 def test_product_path_refuses_cpu_tensors(pkg):
@@ -46,7 +46,8 @@ def test_geometry_validation_without_gpu(pkg):
     t = tab.view(rows, 2)
     # row k = (c, kh, kw): BYTE offset 4*(c*D*H*W + kh*W + kw) ; padded rows are invalid with tap id 63
     assert int(t[0, 0]) == 0 and int(t[4, 0]) == 4 * (1 * 8 + 1) and int(t[9, 0]) == 4 * (4 * 8 * 8)
-    assert (int(t[26, 1]) >> 24) & 1 == 1 and (int(t[27, 1]) >> 24) & 1 == 0 and (int(t[27, 1]) >> 25) & 63 == 63
+    # meta word: tap id in bits 0-5, valid in bit 6, (dd, dh, dw) signed bytes above
+    assert (int(t[26, 1]) >> 6) & 1 == 1 and int(t[26, 1]) & 63 == 8 and (int(t[27, 1]) >> 6) & 1 == 0 and int(t[27, 1]) & 63 == 63
 
 
 @pytest.mark.parametrize('name,octor', [('R2P1D18', lambda o: o.R2Plus1D(18)), ('S3D', lambda o: o.S3D()),

@@ -30,7 +30,7 @@ class ConvGeom(C.Structure):
     _fields_ = [(n, c_i32) for n in ('N', 'C', 'D', 'H', 'W', 'K', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
                                      'pd', 'ph', 'pw', 'OD', 'OH', 'OW')] + [('x_batch_stride', c_i64)] + \
                [(n, c_i32) for n in ('tune_fwd_bm', 'tune_fwd_splits', 'tune_dgrad_bm', 'tune_dgrad_splits',
-                                     'tune_wgrad_splits', 'tune_reserved')]
+                                     'tune_wgrad_splits', 'tune_wgrad_tile')]
 
 
 class PoolGeom(C.Structure):
@@ -52,6 +52,7 @@ SIGNATURES = {
     'gca_conv_fwd': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'gca_conv_dgrad_ws_bytes': (c_i64, [_GP]),
     'gca_conv_dgrad': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    'gca_conv_wgrad_cfg': (c_i32, [_GP, c_vp]),
     'gca_conv_wgrad_ws_bytes': (c_i64, [_GP]),
     'gca_conv_wgrad': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     'gca_bias_grad': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),

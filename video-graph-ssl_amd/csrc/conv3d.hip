@@ -759,7 +759,7 @@ int gca_conv_pack(const gca_conv_geom* g, int which, const float* w, float* pack
 
 int64_t gca_conv_table_rows(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || which < 0 || which > 2) return GCA_EINVAL;
-  if (which == 2) return gca_round_up((int64_t)g->C * taps(g), TABLE_PAD_W);
+  if (which == 2) return gca_round_up((int64_t)g->C * taps(g) + TABLE_PAD_W, 64);   // any wgrad tile (<= 192 wide) stays inside
   std::vector<ClassInfo> cls;
   build_classes(g, which, cls);
   int64_t n = 0;
@@ -778,7 +778,7 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* t) {
       if (k < kred) {
         const int ch = (int)(k / T), tap = (int)(k % T);
         const int a = tap / (g->kh * g->kw), r = tap % (g->kh * g->kw), b = r / g->kw, c = r % g->kw;
-        off = (int32_t)(ch * DHW + a * HW + (int64_t)b * g->W + c);
+        off = (int32_t)(uint32_t)((uint64_t)((ch * DHW + a * HW + (int64_t)b * g->W + c) * 4) & 0xffffffffu);   // BYTES
         pk = pack_row_meta(a, b, c, 1, tap < 63 ? tap : 63);
       }
       t[2 * k] = off; t[2 * k + 1] = pk;

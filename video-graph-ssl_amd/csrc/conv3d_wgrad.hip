@@ -19,10 +19,10 @@ constexpr int LDW = WBK + 4;       // LDS row pitch in floats (144 B)
 
 typedef gca_magic Magic;
 inline Magic make_magic(unsigned d) { return gca_make_magic(d); }
-__device__ __forceinline__ unsigned fdiv(unsigned n, unsigned /*d*/, Magic g) { return gca_fdiv(n, g); }
 
 struct WgradParams {
   int C, D, H, W, K, OD, OH, OW;
+  int kd, kh, kw;
   int sd, sh, sw, pd, ph, pw;
   int Kred;                 // C*taps  (GEMM N)
   int tilesM, tilesN, splits;
@@ -30,16 +30,37 @@ struct WgradParams {
   int chk;
   unsigned Ktot;            // NB*OD*OH*OW (GEMM K) -- < 2^30
   unsigned x_nstride;       // elements between clips of x
-  unsigned x_bytes, dy_bytes;
+  unsigned x_bytes, dy_bytes, slab_bytes;
   Magic m_osp, m_ohw, m_ow;
 };
 
-template <int BM, int BNW, bool AVEC>
+// Window validity of one spatial position as a bit per tap (bit = 1: tap INSIDE the input), built from per-axis
+// bit rows: kd + kh + kw range tests instead of one test per gathered element.
+template <typename MaskT>
+__device__ __forceinline__ MaskT tap_valid_mask(const WgradParams& p, int id0, int ih0, int iw0, bool chkD, bool chkH, bool chkW) {
+  MaskT vw = (MaskT(1) << p.kw) - 1, vh = (MaskT(1) << p.kh) - 1, vd = (MaskT(1) << p.kd) - 1;
+  if (chkW) { vw = 0; for (int c = 0; c < p.kw; ++c) vw |= (MaskT)((unsigned)(iw0 + c) < (unsigned)p.W) << c; }
+  if (chkH) { vh = 0; for (int b = 0; b < p.kh; ++b) vh |= (MaskT)((unsigned)(ih0 + b) < (unsigned)p.H) << b; }
+  if (chkD) { vd = 0; for (int a = 0; a < p.kd; ++a) vd |= (MaskT)((unsigned)(id0 + a) < (unsigned)p.D) << a; }
+  MaskT hw = vw;
+  if (p.kh > 1) { hw = 0; for (int b = 0; b < p.kh; ++b) hw |= ((vh >> b) & 1) ? vw << (b * p.kw) : MaskT(0); }
+  else if (!(vh & 1)) hw = 0;
+  MaskT all = hw;
+  if (p.kd > 1) { all = 0; const int khw = p.kh * p.kw; for (int a = 0; a < p.kd; ++a) all |= ((vd >> a) & 1) ? hw << (a * khw) : MaskT(0); }
+  else if (!(vd & 1)) all = 0;
+  return all;
+}
+
+// 4 waves arranged WM x WN; every wave owns TM x TN MFMA tiles: block tile = (32*WM*TM) x (32*WN*TN).
+// FAST 1 (<= 31 taps) / 2 (<= 62 taps): the window test is done once per spatial position (a bit per tap) and
+// a gathered element then costs v_bfe + add + or; FAST 0: every element tests its own (dd, dh, dw).
+template <int WM, int WN, int TM, int TN, bool AVEC, int FAST>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const int2* __restrict__ table,
     float* __restrict__ slab, WgradParams p) {
-  constexpr int WM = 2, WN = 2;
-  constexpr int TM = BM / WM / 32, TN = BNW / WN / 32;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(32 * WN * TN <= TABLE_PAD_W, "the row table is padded for tiles up to TABLE_PAD_W columns");
+  constexpr int BM = 32 * WM * TM, BNW = 32 * WN * TN;
   constexpr int A_PER = AVEC ? BM / 32 : BM / 8;     // float4 (4 k) or scalar loads per thread for dY
   constexpr int B_PER = BNW / 8;                     // scalar gathers per thread for X
 
@@ -58,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 
   const int kl = tid & 31, g = tid >> 5;             // B (and scalar A): k lane, row group
   const int kq = tid & 7, ga = tid >> 3;             // vector A: k quad, row group
-  const unsigned OSP = (unsigned)(p.OD * p.OH * p.OW), OHW = (unsigned)(p.OH * p.OW);
+  const unsigned OSP = (unsigned)(p.OD * p.OH * p.OW);
   const int HW = p.H * p.W;
   const bool chkD = p.chk & 1, chkH = p.chk & 2, chkW = p.chk & 4;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
@@ -79,20 +100,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   float areg[AVEC ? 1 : A_PER];
   float4 avec[AVEC ? A_PER : 1];
   float breg[B_PER];
+  const int a_rows_left = p.K - (tileM * BM + (AVEC ? ga : g));     // dY row (32*i | 8*i) of this thread is real iff < this
+  const unsigned a_row0 = (unsigned)(tileM * BM + (AVEC ? ga : g)) * OSP * 4u;
+  const unsigned a_step = (AVEC ? 32u : 8u) * OSP * 4u;
 
   auto load_tiles = [&](int kt) __attribute__((always_inline)) {
     // ---- A: dY[img, m, o]
     if (AVEC) {
       const unsigned kp = (unsigned)kt * WBK + kq * 4;          // 4 consecutive positions, same image (OSP % 4 == 0)
-      const unsigned kc = kp < p.Ktot ? kp : 0u;
-      const unsigned img = fdiv(kc, OSP, p.m_osp);
+      const bool kv4 = kp < p.Ktot;
+      const unsigned kc = kv4 ? kp : 0u;
+      const unsigned img = gca_fdiv(kc, p.m_osp);
       const unsigned o = kc - img * OSP;
-      const unsigned base = (img * (unsigned)p.K * OSP + o) * 4u;
-      const unsigned kinv = kp < p.Ktot ? 0u : 0xffffffffu;
+      const unsigned base = (img * (unsigned)p.K * OSP + o) * 4u + a_row0;
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) {
-        const int m = tileM * BM + ga + 32 * i;
-        const unsigned voff = (base + (unsigned)m * OSP * 4u) | kinv | (m < p.K ? 0u : 0xffffffffu);
+        const unsigned voff = (kv4 && 32 * i < a_rows_left) ? base + (unsigned)i * a_step : 0xffffffffu;
         // whole-vector bit_cast: element-wise __builtin_bit_cast miscompiles to a replicated dword load (ROCm 7.2)
         const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)voff, 0, 0));
         avec[i] = make_float4(f.x, f.y, f.z, f.w);
@@ -102,34 +125,52 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const unsigned kp = (unsigned)kt * WBK + kl;
     const bool kv = kp < p.Ktot;
     const unsigned kc = kv ? kp : 0u;
-    const unsigned img = fdiv(kc, OSP, p.m_osp);
+    const unsigned img = gca_fdiv(kc, p.m_osp);
     const unsigned o = kc - img * OSP;
     if (!AVEC) {
-      const unsigned base = (img * (unsigned)p.K * OSP + o) * 4u;
-      const unsigned kinv = kv ? 0u : 0xffffffffu;
+      const unsigned base = (img * (unsigned)p.K * OSP + o) * 4u + a_row0;
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) {
-        const int m = tileM * BM + g + 8 * i;
-        const unsigned voff = (base + (unsigned)m * OSP * 4u) | kinv | (m < p.K ? 0u : 0xffffffffu);
+        const unsigned voff = (kv && 8 * i < a_rows_left) ? base + (unsigned)i * a_step : 0xffffffffu;
         areg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (int)voff, 0, 0));
       }
     }
     // ---- B: X window element for (c, tap) = table row n'
-    const unsigned od = fdiv(o, OHW, p.m_ohw), r = o - od * OHW;
-    const unsigned oh = fdiv(r, (unsigned)p.OW, p.m_ow), ow = r - oh * (unsigned)p.OW;
+    const unsigned od = gca_fdiv(o, p.m_ohw), r = o - od * p.m_ohw.d;
+    const unsigned oh = gca_fdiv(r, p.m_ow), ow = r - oh * (unsigned)p.OW;
     const int id0 = (int)od * p.sd - p.pd, ih0 = (int)oh * p.sh - p.ph, iw0 = (int)ow * p.sw - p.pw;
     const unsigned bbase = (img * p.x_nstride + (unsigned)(id0 * HW + ih0 * p.W + iw0)) * 4u;
+    if (FAST == 1) {
+      const unsigned inval = kv ? ~tap_valid_mask<unsigned>(p, id0, ih0, iw0, chkD, chkH, chkW) : 0xffffffffu;
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) {
-      const int2 e = Ts[g + 8 * j];
-      int off, dd, dh, dw, rvalid;
-      decode_row(e, off, dd, dh, dw, rvalid);
-      bool ok = kv & (rvalid != 0);
-      if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.D);
-      if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.H);
-      if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.W);
-      const unsigned voff = (bbase + (unsigned)off * 4u) | (ok ? 0u : 0xffffffffu);
-      breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
+      for (int j = 0; j < B_PER; ++j) {
+        const int2 e = Ts[g + 8 * j];                                     // x: byte offset, y: tap id in the low bits
+        const unsigned voff = (bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)inval, e.y, 1);
+        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
+      }
+    } else if (FAST == 2) {
+      const unsigned long long inval = kv ? ~tap_valid_mask<unsigned long long>(p, id0, ih0, iw0, chkD, chkH, chkW) : ~0ull;
+      const unsigned ilo = (unsigned)inval, ihi = (unsigned)(inval >> 32);
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) {
+        const int2 e = Ts[g + 8 * j];
+        const unsigned m = (e.y & 32) ? ihi : ilo;
+        const unsigned voff = (bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)m, e.y, 1);
+        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) {
+        const int2 e = Ts[g + 8 * j];
+        int off, dd, dh, dw, rvalid;
+        decode_row(e, off, dd, dh, dw, rvalid);
+        bool ok = kv & (rvalid != 0);
+        if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.D);
+        if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.H);
+        if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.W);
+        const unsigned voff = (bbase + (unsigned)off) | (ok ? 0u : 0xffffffffu);
+        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
+      }
     }
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
@@ -173,16 +214,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     __syncthreads();
   }
 
+  // ---- epilogue: partial tile -> slab[split][m][n] through a buffer resource (one 32-bit offset per column
+  // tile, wave-uniform row part in soffset, all-ones offset = dropped store)
   float* out = slab + (long long)split * p.K * p.Kred;
+  const __amdgpu_buffer_rsrc_t ro_ = __builtin_amdgcn_make_buffer_rsrc(out, 0, p.slab_bytes, 0x00020000);
+  const int m0 = tileM * BM + wm * (TM * 32) + 4 * lh;
+  const int rows_left = p.K - m0;
+  const unsigned rowb = (unsigned)p.Kred * 4u;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = tileN * BNW + wn * (TN * 32) + j * 32 + ll;
+    const unsigned vb = n < p.Kred ? ((unsigned)m0 * (unsigned)p.Kred + (unsigned)n) * 4u : 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = tileM * BM + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.K && n < p.Kred) out[(long long)m * p.Kred + n] = acc[i][j][r];
+        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+        const unsigned vo = ro < rows_left ? vb : 0xffffffffu;
+        const float v = acc[i][j][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ro_, (int)vo, (int)((unsigned)ro * rowb), 0);
       }
   }
 }
@@ -212,9 +262,30 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, long long N, long
   if (threadIdx.x == 0) db[k] = accumulate ? db[k] + s : s;
 }
 
-void wgrad_plan(const gca_conv_geom* g, WgradParams& p, bool& bm64, bool& bn64, bool& avec) {
+// Tile shapes (rows = output channels, cols = C*taps).  Index = gca_conv_geom.tune_wgrad_tile (0 = heuristic).
+struct WgradShape { int bm, bn, wm, wn, tm, tn; };
+constexpr int N_WGRAD_SHAPES = 10;
+const WgradShape WGRAD_SHAPES[N_WGRAD_SHAPES + 1] = {
+    {0, 0, 0, 0, 0, 0},
+    {64, 64, 2, 2, 1, 1},  {64, 128, 2, 2, 1, 2},  {128, 64, 2, 2, 2, 1},  {128, 128, 2, 2, 2, 2},   // 1..4
+    {96, 128, 1, 4, 3, 1}, {160, 128, 1, 4, 5, 1}, {128, 96, 4, 1, 1, 3},  {128, 160, 4, 1, 1, 5},   // 5..8
+    {64, 192, 2, 2, 1, 3}, {192, 64, 2, 2, 3, 1}};                                                    // 9..10
+
+inline int wgrad_fast(const gca_conv_geom* g) { const int t = taps(g); return t <= 31 ? 1 : (t <= 62 ? 2 : 0); }
+inline bool wgrad_shape_ok(int idx, int fast) {
+  if (idx < 1 || idx > N_WGRAD_SHAPES) return false;
+  if (fast == 1) return true;
+  if (fast == 2) return idx == 3 || idx == 4 || idx == 7 || idx == 8;       // instantiated for the 7x7 stem family
+  return idx <= 4;
+}
+
+struct WgradPlan { WgradParams p; int shape; bool avec; int fast; };
+
+void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
+  WgradParams& p = pl.p;
   p.C = g->C; p.D = g->D; p.H = g->H; p.W = g->W; p.K = g->K;
   p.OD = g->OD; p.OH = g->OH; p.OW = g->OW;
+  p.kd = g->kd; p.kh = g->kh; p.kw = g->kw;
   p.sd = g->sd; p.sh = g->sh; p.sw = g->sw; p.pd = g->pd; p.ph = g->ph; p.pw = g->pw;
   p.Kred = g->C * taps(g);
   const long long osp = (long long)g->OD * g->OH * g->OW;
@@ -222,22 +293,35 @@ void wgrad_plan(const gca_conv_geom* g, WgradParams& p, bool& bm64, bool& bn64, 
   const long long cdhw = (long long)g->C * g->D * g->H * g->W;
   p.x_nstride = (unsigned)(g->x_batch_stride ? g->x_batch_stride : cdhw);
   const long long xb = (long long)g->N * p.x_nstride * 4, yb = (long long)g->N * g->K * osp * 4;
+  const long long sb = (long long)g->K * p.Kred * 4;
   p.x_bytes = xb > 0xfffff000LL ? 0xfffff000u : (unsigned)xb;
   p.dy_bytes = yb > 0xfffff000LL ? 0xfffff000u : (unsigned)yb;
+  p.slab_bytes = sb > 0xfffff000LL ? 0xfffff000u : (unsigned)sb;
   p.m_osp = make_magic((unsigned)osp);
   p.m_ohw = make_magic((unsigned)(g->OH * g->OW));
   p.m_ow = make_magic((unsigned)g->OW);
-  avec = osp % 4 == 0;
-  auto small = [](int dk) {
-    if (dk <= 64) return true;
-    const int t128 = (int)gca_ceil_div(dk, 128) * 128, t64 = (int)gca_ceil_div(dk, 64) * 64;
-    return (t128 - dk) * 4 > t128 && t64 < t128;
-  };
-  bm64 = small(g->K);
-  bn64 = small(p.Kred);
-  p.tilesM = (int)gca_ceil_div(g->K, bm64 ? 64 : 128);
-  p.tilesN = (int)gca_ceil_div(p.Kred, bn64 ? 64 : 128);
+  pl.avec = osp % 4 == 0;
+  pl.fast = wgrad_fast(g);
   p.kt_total = (int)gca_ceil_div((long long)p.Ktot, WBK);
+  // tile shape: least padded MFMA work, discounted for how well a shape amortises its gathers
+  int best = 0;
+  if (wgrad_shape_ok(g->tune_wgrad_tile, pl.fast)) best = g->tune_wgrad_tile;
+  else {
+    double best_cost = 1e300;
+    for (int i = 1; i <= N_WGRAD_SHAPES; ++i) {
+      if (!wgrad_shape_ok(i, pl.fast)) continue;
+      const WgradShape& sh = WGRAD_SHAPES[i];
+      const double padded = (double)gca_round_up(g->K, sh.bm) * (double)gca_round_up(p.Kred, sh.bn);
+      const double eff = (sh.bm * sh.bn >= 128 * 96 ? 1.0 : (sh.bm * sh.bn >= 64 * 128 ? 0.92 : 0.8)) *
+                         ((sh.bm + sh.bn) > 256 ? 0.9 : 1.0);            // > 64 KiB of LDS: one workgroup per CU
+      const double cost = padded / eff;
+      if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+  }
+  pl.shape = best;
+  const WgradShape& sh = WGRAD_SHAPES[best];
+  p.tilesM = (int)gca_ceil_div(g->K, sh.bm);
+  p.tilesN = (int)gca_ceil_div(p.Kred, sh.bn);
   const long long tiles = (long long)p.tilesM * p.tilesN;
   long long want = gca_ceil_div(1024, tiles);                 // aim for ~4 workgroups per CU
   long long maxs = p.kt_total / 4 > 0 ? p.kt_total / 4 : 1;   // >= 4 k-tiles per split
@@ -252,11 +336,29 @@ void wgrad_plan(const gca_conv_geom* g, WgradParams& p, bool& bm64, bool& bn64, 
           ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
 }
 
-template <int BM, int BNW>
+template <int WM, int WN, int TM, int TN, int FAST>
 void launch_w(bool avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
               const WgradParams& p) {
-  if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<BM, BNW, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BNW, false>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+}
+
+template <int FAST>
+int launch_shape(int shape, bool avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t,
+                 float* slab, const WgradParams& p) {
+  switch (shape) {
+    case 1: if (FAST != 2) { launch_w<2, 2, 1, 1, FAST == 2 ? 1 : FAST>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 2: if (FAST != 2) { launch_w<2, 2, 1, 2, FAST == 2 ? 1 : FAST>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 3: launch_w<2, 2, 2, 1, FAST>(avec, grid, st, x, dy, t, slab, p); return 0;
+    case 4: launch_w<2, 2, 2, 2, FAST>(avec, grid, st, x, dy, t, slab, p); return 0;
+    case 5: if (FAST == 1) { launch_w<1, 4, 3, 1, 1>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 6: if (FAST == 1) { launch_w<1, 4, 5, 1, 1>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 7: if (FAST != 0) { launch_w<4, 1, 1, 3, FAST == 0 ? 1 : FAST>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 8: if (FAST != 0) { launch_w<4, 1, 1, 5, FAST == 0 ? 1 : FAST>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 9: if (FAST == 1) { launch_w<2, 2, 1, 3, 1>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+    case 10: if (FAST == 1) { launch_w<2, 2, 3, 1, 1>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
+  }
+  return GCA_EINVAL;
 }
 
 }  // namespace
@@ -265,27 +367,39 @@ extern "C" {
 
 int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g) {
   if (!geom_ok(g)) return GCA_EINVAL;
-  WgradParams p{}; bool a, b, v;
-  wgrad_plan(g, p, a, b, v);
-  return (int64_t)p.splits * g->K * p.Kred * (int64_t)sizeof(float);
+  WgradPlan pl{};
+  wgrad_plan(g, pl);
+  return (int64_t)pl.p.splits * g->K * pl.p.Kred * (int64_t)sizeof(float);
+}
+
+/* out4 = {tile rows, tile cols, split-K factor, shape index | float4-dY<<8 | tap-mask kind<<9} */
+int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
+  if (!geom_ok(g) || !out4) return GCA_EINVAL;
+  WgradPlan pl{};
+  wgrad_plan(g, pl);
+  out4[0] = WGRAD_SHAPES[pl.shape].bm; out4[1] = WGRAD_SHAPES[pl.shape].bn; out4[2] = pl.p.splits;
+  out4[3] = pl.shape | (pl.avec << 8) | (pl.fast << 9);
+  return GCA_OK;
 }
 
 int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream) {
   if (!geom_ok(g) || !x || !dy || !table || !dw || !ws) return GCA_EINVAL;
-  WgradParams p{}; bool bm64, bn64, avec;
-  wgrad_plan(g, p, bm64, bn64, avec);
+  WgradPlan pl{};
+  wgrad_plan(g, pl);
+  const WgradParams& p = pl.p;
   hipStream_t st = (hipStream_t)stream;
   const long long nblk = (long long)p.tilesM * p.tilesN * p.splits;
   if (nblk > 0x7fffffffLL) return GCA_EINVAL;
   const int2* t = reinterpret_cast<const int2*>(table);
   float* slab = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)nblk);
-  if (bm64 && bn64) launch_w<64, 64>(avec, grid, st, x, dy, t, slab, p);
-  else if (bm64) launch_w<64, 128>(avec, grid, st, x, dy, t, slab, p);
-  else if (bn64) launch_w<128, 64>(avec, grid, st, x, dy, t, slab, p);
-  else launch_w<128, 128>(avec, grid, st, x, dy, t, slab, p);
-  int rc = gca_launch_status();
+  int rc;
+  if (pl.fast == 1) rc = launch_shape<1>(pl.shape, pl.avec, grid, st, x, dy, t, slab, p);
+  else if (pl.fast == 2) rc = launch_shape<2>(pl.shape, pl.avec, grid, st, x, dy, t, slab, p);
+  else rc = launch_shape<0>(pl.shape, pl.avec, grid, st, x, dy, t, slab, p);
+  if (rc) return rc;
+  rc = gca_launch_status();
   if (rc) return rc;
   const long long n = (long long)g->K * p.Kred;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 256)), dim3(256), 0, st, slab, dw, n,

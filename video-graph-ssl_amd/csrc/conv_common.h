@@ -10,7 +10,7 @@ namespace gca_conv {
 constexpr int BK = 16;          // GEMM-K tile of the forward/dgrad kernels
 constexpr int WBK = 32;         // GEMM-K (spatial) tile of the wgrad kernel
 constexpr int MPAD = 64;        // packed weights: M padded to this
-constexpr int TABLE_PAD_W = 128;
+constexpr int TABLE_PAD_W = 192;   // widest wgrad tile: the table holds this many invalid rows past C*taps
 constexpr int FAST_MAX_TAPS = 62;
 constexpr int NUM_CU = 256;
 
@@ -59,6 +59,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   if (in_elems >= (1LL << 30) || out_elems >= (1LL << 30)) return false;
   for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && (v >> 10) <= 1)) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
+  if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 10) return false;
   return true;
 }
 

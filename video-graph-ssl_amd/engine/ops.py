@@ -98,8 +98,32 @@ class ConvPlan:
 
     def cfg(self, which):
         out = (C.c_int32 * 4)()
-        H.call('gca_conv_kernel_cfg', self.gp, which, out)
+        if which == 2:
+            H.call('gca_conv_wgrad_cfg', self.gp, out)
+        else:
+            H.call('gca_conv_kernel_cfg', self.gp, which, out)
         return tuple(out)
+
+    WGRAD_SHAPES = {1: (64, 64), 2: (64, 128), 3: (128, 64), 4: (128, 128), 5: (96, 128), 6: (160, 128), 7: (128, 96),
+                    8: (128, 160), 9: (64, 192), 10: (192, 64)}
+
+    def _wgrad_candidates(self, M, Nred, kt):
+        """(tile shape index, split) pairs.  Shapes whose padding multiplies mostly zeros are skipped; the kernel
+        refuses shapes it was not built for (the tuner then just skips them)."""
+        cands = []
+        least = min(-(-M // bm) * bm * -(-Nred // bn) * bn for bm, bn in self.WGRAD_SHAPES.values())
+        for idx, (bm, bn) in self.WGRAD_SHAPES.items():
+            padded = -(-M // bm) * bm * -(-Nred // bn) * bn
+            if padded > 1.25 * least:
+                continue
+            tiles = -(-M // bm) * -(-Nred // bn)
+            base = max(1, min(kt // 4, 1024 // max(1, tiles)))
+            for f in (0.5, 1, 2):
+                sp = max(1, min(kt, 1024, int(base * f)))
+                if sp * M * Nred * 4 > (256 << 20):
+                    continue
+                cands.append((idx, sp))
+        return sorted(set(cands))
 
     # ---- one-off launch tuning ------------------------------------------------------------
     def _igemm_candidates(self, M, Ntot, kred):
@@ -134,9 +158,7 @@ class ConvPlan:
         elif which == 1:
             cands = self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)
         else:
-            kt = -(-(N * OD * OH * OW) // 32)
-            base = max(1, min(kt // 4, 1024 // max(1, (-(-K // 128)) * (-(-(g.C * self.taps) // 128)))))
-            cands = sorted(set(max(1, min(kt, int(base * f))) for f in (0.25, 0.5, 1, 2, 4)))
+            cands = self._wgrad_candidates(K, g.C * self.taps, -(-(N * OD * OH * OW) // 32))
         best, best_t = None, None
         for c in cands:
             if which == 0:
@@ -144,8 +166,10 @@ class ConvPlan:
             elif which == 1:
                 g.tune_dgrad_bm, g.tune_dgrad_splits = c
             else:
-                g.tune_wgrad_splits = c
+                g.tune_wgrad_tile, g.tune_wgrad_splits = c
             self.refresh()
+            if which == 2 and self.cfg(2)[3] & 255 != c[0]:      # shape not available for this tap count
+                continue
             try:
                 t = _time_ms(run)
             except RuntimeError:
@@ -158,7 +182,9 @@ class ConvPlan:
             elif which == 1:
                 g.tune_dgrad_bm, g.tune_dgrad_splits = best
             else:
-                g.tune_wgrad_splits = best
+                g.tune_wgrad_tile, g.tune_wgrad_splits = best
+        elif which == 2:
+            g.tune_wgrad_tile, g.tune_wgrad_splits = 0, 0
         self.refresh()
 
 
