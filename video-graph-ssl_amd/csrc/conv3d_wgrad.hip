@@ -54,7 +54,10 @@ __device__ __forceinline__ MaskT tap_valid_mask(const WgradParams& p, int id0, i
 // 4 waves arranged WM x WN; every wave owns TM x TN MFMA tiles: block tile = (32*WM*TM) x (32*WN*TN).
 // FAST 1 (<= 31 taps) / 2 (<= 62 taps): the window test is done once per spatial position (a bit per tap) and
 // a gathered element then costs v_bfe + add + or; FAST 0: every element tests its own (dd, dh, dw).
-template <int WM, int WN, int TM, int TN, bool AVEC, int FAST>
+// BVEC (pointwise-in-space convs: kh = kw = 1, unit spatial stride, no spatial padding): a table row's 4
+// consecutive positions are 4 consecutive floats of X, so the gather uses float4 loads too (and shares the
+// position arithmetic with the dY loads).
+template <int WM, int WN, int TM, int TN, bool AVEC, int FAST, bool BVEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const int2* __restrict__ table,
     float* __restrict__ slab, WgradParams p) {
@@ -62,7 +65,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   static_assert(32 * WN * TN <= TABLE_PAD_W, "the row table is padded for tiles up to TABLE_PAD_W columns");
   constexpr int BM = 32 * WM * TM, BNW = 32 * WN * TN;
   constexpr int A_PER = AVEC ? BM / 32 : BM / 8;     // float4 (4 k) or scalar loads per thread for dY
-  constexpr int B_PER = BNW / 8;                     // scalar gathers per thread for X
+  constexpr int B_PER = BVEC ? BNW / 32 : BNW / 8;   // float4 or scalar gathers per thread for X
+  static_assert(!BVEC || (AVEC && FAST == 1), "BVEC needs the float4 position mapping and the 32-bit tap mask");
 
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDW];
   __shared__ __attribute__((aligned(16))) float Bs[2][BNW][LDW];
@@ -99,7 +103,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 
   float areg[AVEC ? 1 : A_PER];
   float4 avec[AVEC ? A_PER : 1];
-  float breg[B_PER];
+  float breg[BVEC ? 1 : B_PER];
+  float4 bvec[BVEC ? B_PER : 1];
   const int a_rows_left = p.K - (tileM * BM + (AVEC ? ga : g));     // dY row (32*i | 8*i) of this thread is real iff < this
   const unsigned a_row0 = (unsigned)(tileM * BM + (AVEC ? ga : g)) * OSP * 4u;
   const unsigned a_step = (AVEC ? 32u : 8u) * OSP * 4u;
@@ -119,6 +124,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         // whole-vector bit_cast: element-wise __builtin_bit_cast miscompiles to a replicated dword load (ROCm 7.2)
         const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)voff, 0, 0));
         avec[i] = make_float4(f.x, f.y, f.z, f.w);
+      }
+      if (BVEC) {                                               // X rows for the same 4 positions
+        const unsigned od = gca_fdiv(o, p.m_ohw), r = o - od * p.m_ohw.d;
+        const int id0 = (int)od * p.sd - p.pd;
+        const unsigned bbase = (img * p.x_nstride + (unsigned)(id0 * HW) + r) * 4u;
+        const unsigned inval = kv4 ? ~tap_valid_mask<unsigned>(p, id0, 0, 0, chkD, false, false) : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) {
+          const int2 e = Ts[ga + 32 * j];
+          const unsigned voff = (bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)inval, e.y, 1);
+          const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0));
+          bvec[j] = make_float4(f.x, f.y, f.z, f.w);
+        }
+        return;
       }
     }
     // ---- per-lane spatial position of the B column (and of scalar A)
@@ -181,8 +200,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) As[buf][g + 8 * i][kl] = areg[i];
     }
+    if (BVEC) {
 #pragma unroll
-    for (int j = 0; j < B_PER; ++j) Bs[buf][g + 8 * j][kl] = breg[j];
+      for (int j = 0; j < B_PER; ++j) *reinterpret_cast<float4*>(&Bs[buf][ga + 32 * j][kq * 4]) = bvec[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) Bs[buf][g + 8 * j][kl] = breg[j];
+    }
   };
 
   if (kt0 < kt1) {
@@ -279,7 +303,7 @@ inline bool wgrad_shape_ok(int idx, int fast) {
   return idx <= 4;
 }
 
-struct WgradPlan { WgradParams p; int shape; bool avec; int fast; };
+struct WgradPlan { WgradParams p; int shape; bool avec; int fast; bool bvec; };
 
 void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   WgradParams& p = pl.p;
@@ -302,6 +326,8 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   p.m_ow = make_magic((unsigned)g->OW);
   pl.avec = osp % 4 == 0;
   pl.fast = wgrad_fast(g);
+  pl.bvec = pl.avec && pl.fast == 1 && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0 &&
+            (g->OH * g->OW) % 4 == 0 && cdhw % 4 == 0 && p.x_nstride % 4 == 0;
   p.kt_total = (int)gca_ceil_div((long long)p.Ktot, WBK);
   // tile shape: least padded MFMA work, discounted for how well a shape amortises its gathers
   int best = 0;
@@ -337,14 +363,16 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
 }
 
 template <int WM, int WN, int TM, int TN, int FAST>
-void launch_w(bool avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
-              const WgradParams& p) {
-  if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST>), grid, dim3(256), 0, st, x, dy, t, slab, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+void launch_w(int avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
+              const WgradParams& p) {      // avec: 0 scalar, 1 float4 dY, 2 float4 dY and X
+  if (avec == 2 && FAST == 1)
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST == 1 ? 1 : 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  else if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST, false>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST, false>), grid, dim3(256), 0, st, x, dy, t, slab, p);
 }
 
 template <int FAST>
-int launch_shape(int shape, bool avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t,
+int launch_shape(int shape, int avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t,
                  float* slab, const WgradParams& p) {
   switch (shape) {
     case 1: if (FAST != 2) { launch_w<2, 2, 1, 1, FAST == 2 ? 1 : FAST>(avec, grid, st, x, dy, t, slab, p); return 0; } break;
@@ -378,7 +406,7 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
   WgradPlan pl{};
   wgrad_plan(g, pl);
   out4[0] = WGRAD_SHAPES[pl.shape].bm; out4[1] = WGRAD_SHAPES[pl.shape].bn; out4[2] = pl.p.splits;
-  out4[3] = pl.shape | (pl.avec << 8) | (pl.fast << 9);
+  out4[3] = pl.shape | (pl.avec << 8) | (pl.fast << 9) | (pl.bvec << 11);
   return GCA_OK;
 }
 
@@ -395,9 +423,10 @@ int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, cons
   float* slab = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)nblk);
   int rc;
-  if (pl.fast == 1) rc = launch_shape<1>(pl.shape, pl.avec, grid, st, x, dy, t, slab, p);
-  else if (pl.fast == 2) rc = launch_shape<2>(pl.shape, pl.avec, grid, st, x, dy, t, slab, p);
-  else rc = launch_shape<0>(pl.shape, pl.avec, grid, st, x, dy, t, slab, p);
+  const int av = !pl.avec || ((uintptr_t)dy % 16) ? 0 : (pl.bvec && ((uintptr_t)x % 16) == 0 ? 2 : 1);
+  if (pl.fast == 1) rc = launch_shape<1>(pl.shape, av, grid, st, x, dy, t, slab, p);
+  else if (pl.fast == 2) rc = launch_shape<2>(pl.shape, av, grid, st, x, dy, t, slab, p);
+  else rc = launch_shape<0>(pl.shape, av, grid, st, x, dy, t, slab, p);
   if (rc) return rc;
   rc = gca_launch_status();
   if (rc) return rc;
