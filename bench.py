@@ -103,7 +103,7 @@ def conv_layers_of(model, x_shape, pkg):
 
 def _sym(c):
     """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10}."""
-    vec, fast = (c[3] >> 10) & 1, (c[3] >> 8) & 3
+    vec, fast = c[1] == 256, (c[3] >> 8) & 3       # bit 10 only says the class COULD use float4 gathers
     return 'conv_igemm_kernel<%d,%d,%d,%s>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false')
 
 
@@ -115,6 +115,12 @@ def kernel_timing(pkg, trainer, args):
     b = args.batch
     enc = trainer.model.model.encoder.base_model
     layers = conv_layers_of(enc, (b, 3, args.frames, args.size, args.size), pkg)
+    # the projection head's Linear layers run on the same kernels (a Linear is a 1x1x1 conv over a 1x1x1 clip)
+    import collections
+    Lin = collections.namedtuple('Lin', 'out_channels kernel_size stride padding weight')
+    for m in trainer.model.modules():
+        if m.__class__.__name__ == 'HipLinear':
+            layers.append((Lin(m.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), m.weight), (b, m.in_features, 1, 1, 1), 0))
     sym = {}
 
     def add(name, ms, flops, times):
@@ -138,6 +144,7 @@ def kernel_timing(pkg, trainer, args):
         c0 = plan.cfg(0)
         add(_sym(c0), t, flops, 2)   # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
+            # (the head's first Linear does: its input is the encoder feature)
             t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
             c1 = plan.cfg(1)
             add(_sym(c1), t, flops, 1)
@@ -155,10 +162,28 @@ def kernel_timing(pkg, trainer, args):
     dom = max(sym, key=lambda k: sym[k][0])
     ach = table[dom]['tflops']
     roof = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom),
                 avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4), launches_per_step=sym[dom][2],
                 flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1))
     return roof, table
+
+
+def pmc_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes of this same workload
+    (profiles/pmc_traffic.json, produced by tools/pmc_step.sh + tools/pmc_parse.py: separate FETCH_SIZE and
+    WRITE_SIZE passes; gfx950 correction 2x FETCH_SIZE, calibrated in that file on the EMA/SGD kernels).
+    None when the profile has no entry for this kernel (different launch configuration than profiled)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    try:
+        with open(path) as f:
+            prof = json.load(f)['kernels']
+    except (OSError, ValueError, KeyError):
+        return None
+    norm = lambda s: s.replace(' ', '')
+    for k, v in prof.items():
+        if norm(k) == norm(symbol) and v.get('launches'):
+            return round((2.0 * v['fetch_raw'] + v['write_raw']) / v['launches'], 1)
+    return None
 
 
 def infonce_timing(pkg, b=32):
@@ -258,6 +283,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    # Launch configurations measured on an MI355X and committed next to the profiles: same kernels every run
+    # (what profiles/ describes) and no measuring at start-up.  Anything missing or stale is re-measured.
+    seed = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'tune_cache.json')
+    if 'GCA_TUNE_CACHE' not in os.environ and os.path.exists(seed):
+        import shutil, tempfile
+        tmp = os.path.join(tempfile.gettempdir(), 'gca_tune_cache_%d_%d.json' % (os.getuid(), rank))
+        shutil.copyfile(seed, tmp)
+        os.environ['GCA_TUNE_CACHE'] = tmp
     pkg = importlib.import_module('video-graph-ssl_amd')
     ctx = pkg.parallel.DistCtx()
     if world > 1:

@@ -5,8 +5,17 @@ import re
 import sqlite3
 import sys
 
-db = sqlite3.connect(sys.argv[1])
-rows = list(db.execute("select name, start, end, vgpr_count, accum_vgpr_count, lds_size from kernels order by start"))
+if sys.argv[1].endswith('.csv'):          # rocprofv3 --kernel-trace --output-format csv
+    import csv
+    rows = []
+    with open(sys.argv[1]) as f:
+        for r in csv.DictReader(f):
+            rows.append((r['Kernel_Name'], int(r['Start_Timestamp']), int(r['End_Timestamp']), int(r['VGPR_Count']),
+                         int(r['Accum_VGPR_Count']), int(r['LDS_Block_Size'])))
+    rows.sort(key=lambda r: r[1])
+else:                                     # rocpd database (default output of rocprofv3 on ROCm 7.2)
+    db = sqlite3.connect(sys.argv[1])
+    rows = list(db.execute("select name, start, end, vgpr_count, accum_vgpr_count, lds_size from kernels order by start"))
 sgd = [i for i, r in enumerate(rows) if '::sgd_kernel' in r[0]]
 steps = []
 for a, b in zip(sgd[:-1], sgd[1:]):
@@ -29,6 +38,6 @@ for dur, a, b in steady:
 n = len(steady)
 busy = sum(v[1] for v in agg.values())
 print('steady steps: %d  dispatches/step: %d  wall/step %.3f ms  kernel-busy/step %.3f ms' % (n, cnt, wall / n / 1e6, busy / n / 1e6))
-print('%-48s %7s %10s %7s %9s  vgpr agpr lds' % ('kernel', 'calls', 'ms/step', '%', 'avg_us'))
+print('%-56s %7s %10s %7s %9s  vgpr agpr lds' % ('kernel', 'calls', 'ms/step', '%', 'avg_us'))
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-    print('%-48s %7.1f %10.4f %7.2f %9.2f  %s' % (k[:48], c / n, t / n / 1e6, 100 * t / busy, t / c / 1e3, regs[k]))
+    print('%-56s %7.1f %10.4f %7.2f %9.2f  %s' % (k[:56], c / n, t / n / 1e6, 100 * t / busy, t / c / 1e3, regs[k]))

@@ -18,7 +18,8 @@ __host__ __device__ inline long long stats_parts(long long N, long long C, long 
 
 // grid (P, C): block (part, c) reduces a contiguous slice of channel c's N*SP elements.
 // `f(i_global)` style is avoided: we walk (n, sp) so reads stay contiguous inside a plane.
-template <int MODE>   // 0: sum x, x^2     1: sum dz, dz*xhat (backward)
+// VEC = 4 (SP % 4 == 0, 16-byte aligned operands): float4 loads, two of them in flight per tensor.
+template <int MODE, int VEC>   // MODE 0: sum x, x^2     1: sum dz, dz*xhat (backward)
 __global__ __launch_bounds__(256) void bn_reduce_kernel(
     const float* __restrict__ a, const float* __restrict__ z, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
@@ -27,7 +28,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
   __shared__ double sh[4];
   const int c = blockIdx.y, part = blockIdx.x;
   const long long M = N * SP;
-  const long long per = (M + P - 1) / P;
+  long long per = (M + P - 1) / P;
+  if (VEC == 4) per = (per + 3) & ~3LL;              // slices start on float4 boundaries
   const long long lo = part * per;
   long long hi = lo + per; if (hi > M) hi = M;
   // fp64 accumulators: these sums cancel heavily (a BN output gradient is nearly zero-mean), and ATen's CPU
@@ -35,6 +37,42 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
   double s0 = 0.0, s1 = 0.0;
   float mu = 0.f, is = 0.f;
   if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+  if (VEC == 4) {
+    auto accum = [&](const float4 av, const float4 zv, const float4 xv) __attribute__((always_inline)) {
+      const float ae[4] = {av.x, av.y, av.z, av.w}, ze[4] = {zv.x, zv.y, zv.z, zv.w}, xe[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (MODE == 0) { const double v = (double)ae[e]; s0 += v; s1 += v * v; }
+        else {
+          float dz = ae[e];
+          if (relu && !(ze[e] > 0.f)) dz = 0.f;
+          s0 += (double)dz; s1 += (double)dz * (double)((xe[e] - mu) * is);
+        }
+      }
+    };
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long i = lo + 4LL * threadIdx.x; i < hi; i += 2048) {
+      const long long i2 = i + 1024;
+      const bool two = i2 < hi;
+      const long long n = i / SP, sp = i - n * SP;
+      const long long n2 = two ? i2 / SP : n, sp2 = two ? i2 - n2 * SP : sp;
+      const long long idx = (n * C + c) * SP + sp, idx2 = (n2 * C + c) * SP + sp2;
+      const long long zi = n * zs + c * SP + sp, zi2 = n2 * zs + c * SP + sp2;
+      float4 a0, a1, z0 = zero4, z1 = zero4, x0 = zero4, x1 = zero4;
+      if (MODE == 0) {
+        a0 = *reinterpret_cast<const float4*>(a + idx);
+        a1 = two ? *reinterpret_cast<const float4*>(a + idx2) : zero4;
+      } else {
+        a0 = *reinterpret_cast<const float4*>(a + zi);
+        a1 = two ? *reinterpret_cast<const float4*>(a + zi2) : zero4;
+        if (relu) { z0 = *reinterpret_cast<const float4*>(z + zi); if (two) z1 = *reinterpret_cast<const float4*>(z + zi2); }
+        x0 = *reinterpret_cast<const float4*>(x + idx);
+        x1 = two ? *reinterpret_cast<const float4*>(x + idx2) : make_float4(mu, mu, mu, mu);
+      }
+      accum(a0, z0, x0);
+      if (two) accum(a1, z1, x1);
+    }
+  } else {
   const long long i0 = lo + threadIdx.x;
   const bool walk = SP >= 256;                      // big planes: one division, then walk incrementally
   long long n = i0 / SP, sp = i0 - n * SP;
@@ -51,6 +89,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
       if (relu && !(z[zidx] > 0.f)) dz = 0.f;
       s0 += (double)dz; s1 += (double)dz * (double)((x[idx] - mu) * is);
     }
+  }
   }
   s0 = gca_block_sum256_d(s0, sh);
   s1 = gca_block_sum256_d(s1, sh);
@@ -211,9 +250,14 @@ int gca_bn_stats(const float* x, int64_t N, int64_t C, int64_t SP, float* stat_s
   if (!x || !stat_sum || !stat_sq || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
   const int P = (int)stats_parts(N, C, SP);
   if (parts_out) *parts_out = P;
-  hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
-                     nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P, stat_sum,
-                     stat_sq);
+  if (SP % 4 == 0 && ((uintptr_t)x % 16) == 0)
+    hipLaunchKernelGGL((bn_reduce_kernel<0, 4>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
+                       nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
+                       stat_sum, stat_sq);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<0, 1>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
+                       nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
+                       stat_sum, stat_sq);
   return gca_launch_status();
 }
 
@@ -270,8 +314,12 @@ int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* 
   float* p0 = reinterpret_cast<float*>(ws);
   float* p1 = p0 + (long long)C * P;
   float* coef = p1 + (long long)C * P;
-  hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
-                     save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1);
+  if ((SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x) % 16 == 0))
+    hipLaunchKernelGGL((bn_reduce_kernel<1, 4>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<1, 1>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, p0, p1, P, (double)N * (double)SP,
                      gamma, save_invstd, dgamma, dbeta, coef, (long long)C);
   const long long total = (long long)N * C * SP;

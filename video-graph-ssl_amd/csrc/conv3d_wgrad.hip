@@ -74,8 +74,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int bid = blockIdx.x;
-  const int split = bid % p.splits; bid /= p.splits;
+  // Split-major order on XCD-contiguous ids: the tiles of one K-slice run next to each other on one XCD, so
+  // its dY / X slabs are fetched from HBM once and shared through that XCD's L2 by all the N-tiles.
+  int bid = gca_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = p.tilesM * p.tilesN;
+  const int split = bid / ntile; bid -= split * ntile;
   const int tileM = bid % p.tilesM, tileN = bid / p.tilesM;
 
   if (tid < BNW) Ts[tid] = table[tileN * BNW + tid];

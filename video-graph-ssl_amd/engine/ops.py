@@ -45,6 +45,35 @@ WS = _Workspace()
 # ----------------------------------------------------------------------------- convolution
 AUTOTUNE = os.environ.get('GCA_AUTOTUNE', '1') != '0'
 
+# Measured launch configurations, keyed by (pass, geometry).  GCA_TUNE_CACHE=<file> persists them across runs
+# (loaded at import, written at exit by rank 0): a restarted job, or a profiler pass that must see the same
+# kernels as the run it explains, skips the measurement.
+_TUNE_CACHE = {}
+_TUNE_DIRTY = [False]
+_TUNE_PATH = os.environ.get('GCA_TUNE_CACHE', '')
+
+
+def load_tune_cache(path):
+    import json
+    with open(path) as f:
+        for k, v in json.load(f).items():
+            _TUNE_CACHE[k] = tuple(v)
+
+
+def save_tune_cache(path):
+    import json
+    tmp = '%s.tmp.%d' % (path, os.getpid())
+    with open(tmp, 'w') as f:
+        json.dump({k: list(v) for k, v in sorted(_TUNE_CACHE.items())}, f, indent=0)
+    os.replace(tmp, path)
+
+
+if _TUNE_PATH:
+    import atexit
+    if os.path.exists(_TUNE_PATH):
+        load_tune_cache(_TUNE_PATH)
+    atexit.register(lambda: _TUNE_DIRTY[0] and os.environ.get('RANK', '0') == '0' and save_tune_cache(_TUNE_PATH))
+
 
 def _time_ms(fn, reps=3):
     fn()
@@ -153,6 +182,22 @@ class ConvPlan:
         self.tuned[which] = True
         g = self.g
         N, K, OD, OH, OW = self.out_shape
+        key = '%d:%s' % (which, ','.join(str(int(v)) for v in (g.N, g.C, g.D, g.H, g.W, g.K, g.kd, g.kh, g.kw, g.sd, g.sh,
+                                                                 g.sw, g.pd, g.ph, g.pw, g.x_batch_stride)))
+        key = 'v%d:%s' % (H.lib.gca_version(), key)
+        hit = _TUNE_CACHE.get(key)
+        if hit is not None:
+            if which == 0:
+                g.tune_fwd_bm, g.tune_fwd_splits = hit
+            elif which == 1:
+                g.tune_dgrad_bm, g.tune_dgrad_splits = hit
+            else:
+                g.tune_wgrad_tile, g.tune_wgrad_splits = hit
+            if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0:      # still a valid launch code for this library
+                self.refresh()
+                return
+            g.tune_fwd_bm = g.tune_fwd_splits = g.tune_dgrad_bm = g.tune_dgrad_splits = 0
+            g.tune_wgrad_tile = g.tune_wgrad_splits = 0
         if which == 0:
             cands = self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)
         elif which == 1:
@@ -177,6 +222,8 @@ class ConvPlan:
             if best_t is None or t < best_t:
                 best, best_t = c, t
         if best is not None:
+            _TUNE_CACHE[key] = tuple(int(v) for v in best)
+            _TUNE_DIRTY[0] = True
             if which == 0:
                 g.tune_fwd_bm, g.tune_fwd_splits = best
             elif which == 1:
