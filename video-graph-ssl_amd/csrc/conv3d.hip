@@ -154,48 +154,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   const int ao1 = A_F4 > 1 ? (a_slot(1) >> 2) * p.Kpad + (a_slot(1) & 3) * 4 : 0;
   const int ao2 = A_F4 > 2 ? (a_slot(2) >> 2) * p.Kpad + (a_slot(2) & 3) * 4 : 0;
 
-  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
+  // The next tile's loads are issued in PIECES between the MFMA groups of the current tile (below): a vector
+  // instruction costs its 4-cycle issue slot inside a 64-cycle MFMA shadow, while the same instructions bunched
+  // in front of the MFMA block leave the matrix pipe idle for their whole latency chain (table fetch ->
+  // address arithmetic -> load issue).
+  int2 e[B_PER];                                           // table rows of the tile being fetched (wave-uniform)
+  auto issue_table = [&](int kt) __attribute__((always_inline)) {
+    const int2* trow = table + kt * BK + __builtin_amdgcn_readfirstlane(r0);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) e[i] = trow[i];
+  };
+  auto issue_a = [&](int kt) __attribute__((always_inline)) {
     a0 = *reinterpret_cast<const float4*>(arow + ao0 + kt * BK);
     if (A_F4 > 1) a1 = *reinterpret_cast<const float4*>(arow + ao1 + kt * BK);
     if (A_F4 > 2) a2 = *reinterpret_cast<const float4*>(arow + ao2 + kt * BK);
-    // B: gathered window.  Rows are uniform across the wave: fetch their table entries first (scalar,
-    // one batch), then issue all gathers back to back.
-    const int2* trow = table + kt * BK + __builtin_amdgcn_readfirstlane(r0);
-    int2 e[B_PER];
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) e[i] = trow[i];
-    unsigned voff[B_PER];
-#pragma unroll
-    for (int i = 0; i < B_PER; ++i) {
-      int inv;                                            // 0 = valid, -1 = invalid
-      if (FAST == 1) {
-        inv = __builtin_amdgcn_sbfe((int)ilo, e[i].y, 1);            // bit (y & 31) of the mask, sign extended
-      } else if (FAST == 2) {
-        const unsigned m = (e[i].y & 32) ? ihi : ilo;
-        inv = __builtin_amdgcn_sbfe((int)m, e[i].y, 1);
-      } else {
-        int off, dd, dh, dw, rvalid;
-        decode_row(e[i], off, dd, dh, dw, rvalid);
-        bool k = cvalid & (rvalid != 0);
-        if (chkD) k = k & ((unsigned)(id0 + dd) < (unsigned)p.SD);
-        if (chkH) k = k & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
-        if (chkW) k = k & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
-        inv = k ? 0 : -1;
-      }
-      voff[i] = (cb4 + (unsigned)e[i].x) | (unsigned)inv;      // table offsets are in bytes
-    }
-    if (VEC) {
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
-        // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, v[i]) on the elements makes hipcc
-        // (ROCm 7.2) narrow the load to one dword and replicate it.
-        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[i], 0, 0));
-        bvec[i] = make_float4(f.x, f.y, f.z, f.w);
-      }
+  };
+  auto issue_gather = [&](int i) __attribute__((always_inline)) {      // i: compile-time constant after unrolling
+    int inv;                                              // 0 = valid, -1 = invalid
+    if (FAST == 1) {
+      inv = __builtin_amdgcn_sbfe((int)ilo, e[i].y, 1);              // bit (y & 31) of the mask, sign extended
+    } else if (FAST == 2) {
+      const unsigned hsel = (unsigned)-((e[i].y >> 5) & 1);            // all-ones for taps 32..62
+      const unsigned m = ilo ^ ((ilo ^ ihi) & hsel);
+      inv = __builtin_amdgcn_sbfe((int)m, e[i].y, 1);
     } else {
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) breg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff[i], 0, 0));
+      int off, dd, dh, dw, rvalid;
+      decode_row(e[i], off, dd, dh, dw, rvalid);
+      bool k = cvalid & (rvalid != 0);
+      if (chkD) k = k & ((unsigned)(id0 + dd) < (unsigned)p.SD);
+      if (chkH) k = k & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
+      if (chkW) k = k & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
+      inv = k ? 0 : -1;
     }
+    const unsigned voff = (cb4 + (unsigned)e[i].x) | (unsigned)inv;  // table offsets are in bytes
+    if (VEC) {
+      // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, v[i]) on the elements makes hipcc
+      // (ROCm 7.2) narrow the load to one dword and replicate it.
+      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+      bvec[VEC ? i : 0] = make_float4(f.x, f.y, f.z, f.w);
+    } else {
+      breg[VEC ? 0 : i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+    }
+  };
+  // piece g of the next tile's fetch, placed after MFMA group g (G groups per tile): table rows + A tile
+  // first, then the gathers spread over the following groups, leaving the last group(s) as latency shadow
+  constexpr int G = 2 * TM * TN;
+  constexpr int GSPAN = G > 2 ? G - 2 : 1;                              // groups 1..GSPAN carry the gathers
+  constexpr int GCHUNK = (B_PER + GSPAN - 1) / GSPAN;
+  auto issue_piece = [&](int g, int kt) __attribute__((always_inline)) {
+    if (g == 0) { issue_table(kt); issue_a(kt); }
+    else if (g <= GSPAN) {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i)
+        if (i >= (g - 1) * GCHUNK && i < g * GCHUNK) issue_gather(i);
+    }
+  };
+  auto load_tiles = [&](int kt) __attribute__((always_inline)) {        // everything at once (prologue)
+    issue_table(kt);
+    issue_a(kt);
+#pragma unroll
+    for (int i = 0; i < B_PER; ++i) issue_gather(i);
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
     if (A_F4 > 1 || a_last_ok) *reinterpret_cast<float4*>(&As[buf][a_slot(0) >> 2][(a_slot(0) & 3) * 4]) = a0;
@@ -231,7 +249,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   __syncthreads();
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tiles(kt + 1);
+    const bool more = kt + 1 < kt1;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float4 af[TM], bf[TN];
@@ -247,9 +265,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (kt + 1 < kt1) store_tiles(buf ^ 1);
+    if (more) store_tiles(buf ^ 1);
     __syncthreads();
   }
 
@@ -675,7 +696,7 @@ int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
 
 extern "C" {
 
-int gca_version(void) { return 4; }
+int gca_version(void) { return 5; }
 
 int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return GCA_EINVAL;
