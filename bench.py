@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--layer-table', action='store_true', help='log per-layer conv kernel timings to stderr')
+    ap.add_argument('--workload', default='moco', choices=['moco', 'simsiam'],
+                    help="moco: BASELINE configs[1]/[2] (default, the headline line); simsiam: configs[3] -- "
+                         "configs/visual_simsiam.yaml shape: S3D, 16x224x224, FEAT_DIM 1024, temporal-graph blocks on, 4 clips/GPU")
     return ap.parse_args()
 
 
@@ -210,6 +213,76 @@ def infonce_timing(pkg, b=32):
     return out
 
 
+def graph_timing(pkg, B=4, C=192, T=8, HW=28):
+    """Temporal-graph message passing (TemporalGraphAug GCN einsum + skip, temporal_graph.py:56-64) at the
+    BASELINE configs[3] site: S3D base.5, (B,192,8,28,28), 8-node clip graph.  HBM-bound: read support +
+    write out = 2*B*C*T*H*W*4 bytes."""
+    ops = pkg.engine.ops
+    s_ = torch.randn(B, C, T, HW, HW, device='cuda')
+    adj = torch.softmax(torch.randn(B, T, T, device='cuda'), -1)
+
+    def f():
+        ops.graph_gcn_fwd(adj, s_)
+    g = torch.cuda.CUDAGraph()
+    f()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            f()
+    ms = ev_time_ms(g.replay, 50, 5) / 10
+    bytes_alg = 2 * B * C * T * HW * HW * 4 + B * T * T * 4
+    return dict(shape=[B, C, T, HW, HW], ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2),
+                GBps=round(bytes_alg / 1e9 / (ms / 1e3), 1), hbm_frac=round(bytes_alg / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4),
+                gflops=round(2.0 * B * C * T * T * HW * HW / 1e9 / (ms / 1e3), 1))
+
+
+def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
+    """BASELINE configs[3]: SimSiam pre-training iteration on S3D with the temporal-graph blocks on."""
+    cfg = pkg.get_defaults()
+    cfg.merge_from_list(['MODEL.BACKBONE', 'S3D', 'MODEL.BACKBONE_TYPE', '3D', 'MODEL.DROPOUT', 0.0, 'MODEL.PRETRAINED', False,
+                         'MODEL.AUG_FLAG', True, 'INPUT.VIDEO_LENGTH', 16, 'CONTRAST.MEM_TYPE', 'simsiam',
+                         'CROSS.FEAT_DIM', 1024, 'SOLVER.BASE_LR', 0.06, 'SOLVER.LR_SCHEDULER', 'step',
+                         'SOLVER.STEPS', [80, 120, 160], 'SOLVER.WARMUP_FACTOR', 0.01, 'SOLVER.WARMUP_ITERS', 10,
+                         'SOLVER.MAX_EPOCHS', 200])
+    bsz, size = (args.batch if args.batch != 32 else 4), (args.size if args.size != 112 else 224)
+    tr = pkg.SimSiamTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
+    torch.manual_seed(1 + rank)
+    images = torch.randn(bsz, 6, 16, size, size, device=dev)
+    for i in range(max(args.warmup, 0) + 3):
+        tr.train_step(images)
+        if rank == 0 and i < 4:
+            torch.cuda.synchronize()
+            log('warm-up step %d done' % i)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.train_step(images)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = float(out['loss'].item())
+    if rank != 0:
+        return
+    gt = graph_timing(pkg, bsz, 192, 8, size // 8)
+    res = {'metric': 'pretrain_clips_per_sec', 'value': round(bsz * world * args.steps / dt, 3), 'unit': 'clips/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': 'SimSiam pre-training iteration, S3D + temporal-graph blocks (base.5/9/14), 16-frame %dx%d '
+                                  'clips, %d clips/GPU, FEAT_DIM 1024, predictor MLP, SGD (BASELINE.json configs[3])' % (size, size, bsz),
+                      'global_batch': bsz * world, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph},
+           'final_loss': round(loss, 5),
+           'step_tflops_algorithmic': round(6 * (35.958 if size == 224 else 8.949) * bsz / 1e3 / (dt / args.steps), 3),
+           'roofline': dict(bound='hbm', kernel='tmix_kernel<8> (graph message passing, 8-node clip graph)', achieved=gt['GBps'],
+                            peak=PEAK_HBM_GBPS, unit='GB/s', frac=gt['hbm_frac'], traffic=None, avg_launch_ms=gt['ms'],
+                            algorithmic_MB=gt['algorithmic_MB']),
+           'graph_mix_fwd': gt}
+    print(json.dumps(res))
+
+
 def host_cores():
     """Usable host cores: min(affinity mask, cgroup CPU quota, cpu_count)."""
     n = os.cpu_count() or 1
@@ -302,6 +375,15 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world,      # "nccl" == RCCL on ROCm
                                     device_id=dev)
         ctx = pkg.parallel.DistCtx(rank, world, None, host_staged=rehearsal)
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == 'simsiam':
+        return simsiam_main(args, pkg, dev, ctx, world, rank, barrier)
     K = args.queue or (4096 if world == 1 else 65536)
     cfg = make_cfg(pkg, args, K)
     tr = pkg.MoCoTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
@@ -309,13 +391,6 @@ def main():
         log('trainer built')
     torch.manual_seed(1 + rank)
     images = torch.randn(args.batch, 6, args.frames, args.size, args.size, device=dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for i in range(max(args.warmup, 0) + 3):        # +3: two eager warm-up steps and the hipGraph capture
         tr.train_step(images)
@@ -362,6 +437,7 @@ def main():
         res['infonce_fwd'] = infonce_timing(pkg, 32)
         log('infonce timing done')
         res['infonce_fwd_ms'] = res['infonce_fwd']['K4096']['ms']
+        res['graph_mix_fwd'] = graph_timing(pkg)
     if not args.no_kernel_timing:
         res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
         log('kernel timing done')
