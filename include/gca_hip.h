@@ -227,10 +227,12 @@ int gca_queue_advance(int64_t* ptr_dev, int64_t n, int64_t K, void* stream);
 /* sim = softmax_j( sum_f gq[b,i,f]*gk[b,j,f] ), gq/gk stored (B, Ci, T, HW) as the pooled convs
  * leave them (temporal_graph.py:159-176); then adj_pre = sim * theta(hop(i,j)) within max_hop
  * else 0 (:204-210); then adj = sigmoid((logit(u)+logit(adj_pre))/temperature)  (:187-192,
- * RelaxedBernoulli.rsample with explicit uniforms u).  Any of sim/adj_pre may be NULL. */
+ * RelaxedBernoulli.rsample with explicit uniforms u).  ws: gca_graph_gram_ws_bytes(B, Ci, T, HW) bytes of scratch
+ * for the two-pass (T x F)(F x T) product (NULL = slower one-workgroup-per-entry fallback). */
+int64_t gca_graph_gram_ws_bytes(int64_t B, int64_t C, int64_t T, int64_t HW);
 int gca_graph_adj_fwd(const float* gq, const float* gk, int64_t B, int64_t Ci, int64_t T, int64_t HW,
                       int max_hop, float alpha, float temperature, const float* u,
-                      float* sim, float* adj_pre, float* adj, void* stream);
+                      float* sim, float* adj_pre, float* adj, void* ws, void* stream);
 /* NOTE: dadj is in/out -- it is overwritten with the gradient wrt the pre-softmax similarity. */
 int gca_graph_adj_bwd(const float* dadj, const float* gq, const float* gk, const float* sim,
                       const float* adj_pre, const float* adj, int64_t B, int64_t Ci, int64_t T, int64_t HW,

@@ -82,8 +82,9 @@ SIGNATURES = {
                                     c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'gca_queue_enqueue': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     'gca_queue_advance': (c_i32, [c_vp, c_i64, c_i64, c_vp]),
+    'gca_graph_gram_ws_bytes': (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     'gca_graph_adj_fwd': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp,
-                                  c_vp, c_vp, c_vp]),
+                                  c_vp, c_vp, c_vp, c_vp]),
     'gca_graph_adj_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_i32, c_f32,
                                   c_f32, c_vp, c_vp, c_vp]),
     'gca_graph_gcn_fwd': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp]),

@@ -566,7 +566,6 @@ inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, 
     if (lo < 0 || hi >= lim[d]) chk |= 1 << d;
   }
   p.chk = chk;
-  if (const char* e = getenv("GCA_DEBUG_CHK")) p.chk |= atoi(e);   // experiments only
 }
 
 // ---- launch configuration ------------------------------------------------------------------

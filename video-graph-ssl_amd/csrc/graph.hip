@@ -10,7 +10,57 @@
 
 namespace {
 
-// G[b,i,j] = sum_{c,hw} X[b,c,i,hw] * Y[b,c,j,hw]; one workgroup per (b,i,j).
+// G[b,i,j] = sum_{c,hw} X[b,c,i,hw] * Y[b,c,j,hw]   (the (T x F)(F x T) similarity / adjacency-gradient product).
+// Two passes, both deterministic: gram_tile_kernel<T> -- grid (channel chunks, B); a thread keeps the T frames of
+// X and of Y at its hw position in registers and accumulates the whole T x T outer product, so every input
+// element is read exactly once (HBM-bound: 2*B*C*T*HW*4 bytes); gram_finish_kernel sums the chunk partials.
+template <int T>
+__global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                        int C, int HW, int cper, float* __restrict__ part) {
+  __shared__ float sh[4][T * T];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int c0 = chunk * cper, c1 = min(C, c0 + cper);
+  float acc[T][T];
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) acc[i][j] = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    const float* xp = X + ((long long)(b * C + c) * T) * HW;
+    const float* yp = Y + ((long long)(b * C + c) * T) * HW;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+      float xv[T], yv[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) { xv[t] = xp[t * HW + p]; yv[t] = yp[t * HW + p]; }
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] += xv[i] * yv[j];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < T; ++i)
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+      const float v = gca_wave_sum(acc[i][j]);
+      if (lane == 0) sh[wave][i * T + j] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < T * T)
+    part[((long long)b * gridDim.x + chunk) * (T * T) + threadIdx.x] =
+        sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+__global__ void gram_finish_kernel(const float* __restrict__ part, int nchunk, int TT, int total, float* __restrict__ G) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (b, ij)
+  if (i >= total) return;
+  const int b = i / TT, ij = i - b * TT;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[((long long)b * nchunk + k) * TT + ij];
+  G[i] = s;
+}
+
+// Fallback for node counts other than 2 / 4 / 8: one workgroup per (b,i,j).
 __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                    int C, int T, int HW, float* __restrict__ G) {
   __shared__ float sh[4];
@@ -19,13 +69,35 @@ __global__ __launch_bounds__(256) void gram_kernel(const float* __restrict__ X, 
   const float* yp = Y + ((long long)b * C * T + j) * HW;
   const long long cs = (long long)T * HW;
   float s = 0.f;
-  const int F = C * HW;
-  for (int f = threadIdx.x; f < F; f += 256) {
-    const int c = f / HW, p = f - c * HW;
-    s += xp[c * cs + p] * yp[c * cs + p];
-  }
+  for (int c = 0; c < C; ++c)
+    for (int p = threadIdx.x; p < HW; p += 256) s += xp[c * cs + p] * yp[c * cs + p];
   s = gca_block_sum256(s, sh);
   if (threadIdx.x == 0) G[blockIdx.x] = s;
+}
+
+inline int gram_chunks(long long B, int C) {           // channel chunks so that the grid is ~1024 workgroups
+  long long n = gca_ceil_div(1024, B);
+  if (n > C) n = C;
+  if (n < 1) n = 1;
+  const int cper = (int)gca_ceil_div(C, n);
+  return (int)gca_ceil_div(C, cper);
+}
+inline bool gram_tiled(int T) { return T == 2 || T == 4 || T == 8; }
+inline long long gram_ws_floats(long long B, int C, int T) { return gram_tiled(T) ? B * gram_chunks(B, C) * T * T : 0; }
+
+int launch_gram(const float* X, const float* Y, long long B, int C, int T, int HW, float* G, float* ws, hipStream_t st) {
+  if (!gram_tiled(T) || !ws) {
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(B * T * T)), dim3(256), 0, st, X, Y, C, T, HW, G);
+    return gca_launch_status();
+  }
+  const int nchunk = gram_chunks(B, C), cper = (int)gca_ceil_div(C, nchunk);
+  const dim3 grid((unsigned)nchunk, (unsigned)B);
+  if (T == 2) hipLaunchKernelGGL((gram_tile_kernel<2>), grid, dim3(256), 0, st, X, Y, C, HW, cper, ws);
+  else if (T == 4) hipLaunchKernelGGL((gram_tile_kernel<4>), grid, dim3(256), 0, st, X, Y, C, HW, cper, ws);
+  else hipLaunchKernelGGL((gram_tile_kernel<8>), grid, dim3(256), 0, st, X, Y, C, HW, cper, ws);
+  const int TT = T * T, total = (int)(B * TT);
+  hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0, st, ws, nchunk, TT, total, G);
+  return gca_launch_status();
 }
 
 __device__ __forceinline__ float theta_hop(int h, float alpha) {
@@ -169,12 +241,13 @@ extern "C" {
 
 int gca_graph_adj_fwd(const float* gq, const float* gk, int64_t B, int64_t Ci, int64_t T, int64_t HW,
                       int max_hop, float alpha, float temperature, const float* u,
-                      float* sim, float* adj_pre, float* adj, void* stream) {
+                      float* sim, float* adj_pre, float* adj, void* ws, void* stream) {
   if (!gq || !gk || B <= 0 || Ci <= 0 || T <= 0 || HW <= 0 || temperature <= 0.f) return GCA_EINVAL;
   if (adj && !u) return GCA_EINVAL;
   if (!sim) return GCA_EINVAL;      // sim doubles as the scratch for the raw similarities
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(B * T * T)), dim3(256), 0, st, gq, gk, (int)Ci, (int)T, (int)HW, sim);
+  int rc0 = launch_gram(gq, gk, B, (int)Ci, (int)T, (int)HW, sim, reinterpret_cast<float*>(ws), st);
+  if (rc0) return rc0;
   const int BT = (int)(B * T);
   hipLaunchKernelGGL(adj_fwd_kernel, dim3((unsigned)gca_ceil_div(BT, 64)), dim3(64), 0, st, sim, BT, (int)T, max_hop,
                      alpha, temperature, u, sim, adj_pre, adj);
@@ -205,20 +278,20 @@ int gca_graph_gcn_fwd(const float* adj, const float* s, int64_t B, int64_t C, in
   return launch_tmix(adj, s, B, (int)C, (int)T, (int)HW, 0, 1, out, (hipStream_t)stream);
 }
 
-int64_t gca_graph_gcn_bwd_ws_bytes(int64_t B, int64_t C, int64_t T, int64_t HW) {
-  (void)B; (void)C; (void)T; (void)HW;
-  return 256;
+int64_t gca_graph_gram_ws_bytes(int64_t B, int64_t C, int64_t T, int64_t HW) {
+  (void)HW;
+  if (B <= 0 || C <= 0 || T <= 0) return GCA_EINVAL;
+  return 256 + (int64_t)sizeof(float) * gram_ws_floats(B, (int)C, (int)T);
 }
+int64_t gca_graph_gcn_bwd_ws_bytes(int64_t B, int64_t C, int64_t T, int64_t HW) { return gca_graph_gram_ws_bytes(B, C, T, HW); }
 
 int gca_graph_gcn_bwd(const float* adj, const float* s, const float* dout, int64_t B, int64_t C, int64_t T,
                       int64_t HW, float* ds, float* dadj, void* ws, void* stream) {
-  (void)ws;
   if (!adj || !s || !dout || !ds || B <= 0 || C <= 0 || T <= 0 || HW <= 0) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   int rc = launch_tmix(adj, dout, B, (int)C, (int)T, (int)HW, 1, 1, ds, st);
   if (rc || !dadj) return rc;
-  hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(B * T * T)), dim3(256), 0, st, dout, s, (int)C, (int)T, (int)HW, dadj);
-  return gca_launch_status();
+  return launch_gram(dout, s, B, (int)C, (int)T, (int)HW, dadj, reinterpret_cast<float*>(ws), st);
 }
 
 }  // extern "C"

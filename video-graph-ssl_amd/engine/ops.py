@@ -501,8 +501,9 @@ def graph_adj_fwd(gq, gk, u, max_hop, alpha, temperature):
     B, Ci, T = gq.shape[0], gq.shape[1], gq.shape[2]
     HW = gq.shape[3] * gq.shape[4]
     out = torch.empty((3, B, T, T), dtype=F32, device=gq.device)
+    ws = WS.get(H.lib.gca_graph_gram_ws_bytes(B, Ci, T, HW), gq.device)
     H.call('gca_graph_adj_fwd', ptr(gq), ptr(gk), B, Ci, T, HW, int(max_hop), float(alpha), float(temperature), ptr(u),
-           ptr(out[0]), ptr(out[1]), ptr(out[2]), stream())
+           ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(ws), stream())
     return out[0], out[1], out[2]          # sim, adj_pre, adj
 
 
@@ -526,8 +527,9 @@ def graph_gcn_bwd(adj, s, dout, want_dadj=True):
     B, Cc, T = s.shape[0], s.shape[1], s.shape[2]
     ds = torch.empty_like(s)
     dadj = torch.empty((B, T, T), dtype=F32, device=s.device) if want_dadj else None
+    ws = WS.get(H.lib.gca_graph_gcn_bwd_ws_bytes(B, Cc, T, s.shape[3] * s.shape[4]), s.device) if want_dadj else None
     H.call('gca_graph_gcn_bwd', ptr(adj), ptr(s), ptr(dout), B, Cc, T, s.shape[3] * s.shape[4], ptr(ds), ptr(dadj),
-           None, stream())
+           ptr(ws), stream())
     return ds, dadj
 
 
