@@ -449,3 +449,7 @@ def main():
 
 if __name__ == '__main__':
     main()
+    import gc
+    gc.collect()                      # captured hipGraphs go before the HIP runtime does
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()

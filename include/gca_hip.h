@@ -138,16 +138,17 @@ int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running
  * slice of the concat output (s3d_1.py:96 torch.cat) instead of being copied there. */
 int gca_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
                  int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream);
-/* Backward of the fused op.  dz_in = gradient wrt z; z = saved output (ReLU mask); x = saved conv
- * output.  Writes dx (gradient wrt x), accumulates dgamma/dbeta (+=) and, if dres != NULL,
- * writes (dres_accumulate=0) or adds (=1) the gradient wrt the residual input.
- * ws: gca_bn_bwd_ws_bytes(). */
+/* Backward of the fused op.  dz_in = gradient wrt z; x = saved conv output.  relu: 0 none; 1 mask from the saved
+ * output z (z > 0); 2 mask recomputed from x with the forward's own scale/shift (x*scale+shift > 0) -- z may be
+ * NULL and is not read: one tensor less to stream, valid when no residual was added before the ReLU.
+ * Writes dx (gradient wrt x), accumulates dgamma/dbeta (+=) and, if dres != NULL, writes (dres_accumulate=0) or
+ * adds (=1) the gradient wrt the residual input.  ws: gca_bn_bwd_ws_bytes(). */
 int64_t gca_bn_bwd_ws_bytes(int64_t N, int64_t C, int64_t SP);
 int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* gamma,
                const float* save_mean, const float* save_invstd, int relu,
                int64_t N, int64_t C, int64_t SP, float* dx, float* dgamma, float* dbeta,
                float* dres, int dres_accumulate, int64_t z_batch_stride /* of dz_in and z */,
-               void* ws, void* stream);
+               const float* scale, const float* shift, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling.  MaxPool3d: resnet2p1d.py:178, s3d_1.py:10,13,16,22,87, temporal_graph.py:100

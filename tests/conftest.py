@@ -69,3 +69,14 @@ def rel_err(a, b):
     """max |a-b| / max(|b|) -- the 'relative fp32' measure used for the 1e-3 bar."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_objects():
+    """Drop hipGraphs / trainers of a test before the next one starts (and long before interpreter shutdown: a
+    captured graph destroyed after the HIP runtime has been torn down aborts the process at exit)."""
+    yield
+    import gc
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()

@@ -196,6 +196,10 @@ def test_bn_relu_golden(ops, golden, name):
     dx = ops.bn_bwd(g.t(name + ':dy').to(DEV), z, x, gam, mean, invstd, True, N, Cc, SP, dg, db)
     assert rel_err(dx, g.t(name + ':dx')) < 1e-4
     assert rel_err(dg, g.t(name + ':dg')) < 1e-4 and rel_err(db, g.t(name + ':db')) < 1e-4
+    # relu mode 2: the mask is recomputed from x with the forward's scale/shift instead of being read from z
+    dg2, db2 = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    dx2 = ops.bn_bwd(g.t(name + ':dy').to(DEV), None, x, gam, mean, invstd, 2, N, Cc, SP, dg2, db2, None, False, scale, shift)
+    assert torch.equal(dx2, dx) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 def test_bn_residual_slice_and_odd_sizes(ops):

@@ -24,9 +24,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     const float* __restrict__ a, const float* __restrict__ z, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
     long long N, long long C, long long SP, long long zs, int P, float* __restrict__ out0,
-    float* __restrict__ out1) {
+    float* __restrict__ out1, const float* __restrict__ scale, const float* __restrict__ shift) {
   __shared__ double sh[4];
   const int c = blockIdx.y, part = blockIdx.x;
+  // relu == 2: the ReLU mask is recomputed from the conv output exactly as bn_apply computed it (x*scale+shift > 0)
+  // instead of being read back from z -- one tensor less to stream (valid when nothing was added before the ReLU)
+  const float rsc = relu == 2 ? scale[c] : 0.f, rsf = relu == 2 ? shift[c] : 0.f;
   const long long M = N * SP;
   long long per = (M + P - 1) / P;
   if (VEC == 4) per = (per + 3) & ~3LL;              // slices start on float4 boundaries
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
         if (MODE == 0) { const double v = (double)ae[e]; s0 += v; s1 += v * v; }
         else {
           float dz = ae[e];
-          if (relu && !(ze[e] > 0.f)) dz = 0.f;
+          if (relu == 1 && !(ze[e] > 0.f)) dz = 0.f;
+          if (relu == 2 && !(xe[e] * rsc + rsf > 0.f)) dz = 0.f;
           s0 += (double)dz; s1 += (double)dz * (double)((xe[e] - mu) * is);
         }
       }
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
       } else {
         a0 = *reinterpret_cast<const float4*>(a + zi);
         a1 = two ? *reinterpret_cast<const float4*>(a + zi2) : zero4;
-        if (relu) { z0 = *reinterpret_cast<const float4*>(z + zi); if (two) z1 = *reinterpret_cast<const float4*>(z + zi2); }
+        if (relu == 1) { z0 = *reinterpret_cast<const float4*>(z + zi); if (two) z1 = *reinterpret_cast<const float4*>(z + zi2); }
         x0 = *reinterpret_cast<const float4*>(x + idx);
         x1 = two ? *reinterpret_cast<const float4*>(x + idx2) : make_float4(mu, mu, mu, mu);
       }
@@ -86,8 +90,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     } else {
       const long long zidx = n * zs + c * SP + sp;       // dz / z may be channel slices of a concat buffer
       float dz = a[zidx];
-      if (relu && !(z[zidx] > 0.f)) dz = 0.f;
-      s0 += (double)dz; s1 += (double)dz * (double)((x[idx] - mu) * is);
+      const float xv = x[idx];
+      if (relu == 1 && !(z[zidx] > 0.f)) dz = 0.f;
+      if (relu == 2 && !(xv * rsc + rsf > 0.f)) dz = 0.f;
+      s0 += (double)dz; s1 += (double)dz * (double)((xv - mu) * is);
     }
   }
   }
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ dzin, const float* __restrict__ z, const float* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
     int relu, long long total, long long C, long long SP, long long zs, float* __restrict__ dx,
-    float* __restrict__ dres, int dres_acc) {
+    float* __restrict__ dres, int dres_acc, const float* __restrict__ scale, const float* __restrict__ shift) {
   const long long stride = (long long)gridDim.x * 256 * VEC;
   const bool small = total < (1LL << 31);           // 32-bit index math (the usual case)
   const long long zskip = zs - C * SP;
@@ -206,13 +212,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     else { const long long q = i / SP; n = q / C; c = (int)(q - n * C); }
     const long long zi = i + n * zskip;
     const float A = coef[c], B = coef[C + c], Cc = coef[2 * C + c], mu = mean[c], is = invstd[c];
+    const float rsc = relu == 2 ? scale[c] : 0.f, rsf = relu == 2 ? shift[c] : 0.f;
     if (VEC == 4) {
       float4 d = *reinterpret_cast<const float4*>(dzin + zi);
-      if (relu) {
+      if (relu == 1) {
         const float4 zz = *reinterpret_cast<const float4*>(z + zi);
         if (!(zz.x > 0.f)) d.x = 0.f; if (!(zz.y > 0.f)) d.y = 0.f; if (!(zz.z > 0.f)) d.z = 0.f; if (!(zz.w > 0.f)) d.w = 0.f;
       }
       const float4 xv = *reinterpret_cast<const float4*>(x + i);
+      if (relu == 2) {
+        if (!(xv.x * rsc + rsf > 0.f)) d.x = 0.f; if (!(xv.y * rsc + rsf > 0.f)) d.y = 0.f;
+        if (!(xv.z * rsc + rsf > 0.f)) d.z = 0.f; if (!(xv.w * rsc + rsf > 0.f)) d.w = 0.f;
+      }
       float4 o;
       o.x = A * (d.x - B - (xv.x - mu) * is * Cc);
       o.y = A * (d.y - B - (xv.y - mu) * is * Cc);
@@ -225,8 +236,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       }
     } else {
       float d = dzin[zi];
-      if (relu && !(z[zi] > 0.f)) d = 0.f;
-      dx[i] = A * (d - B - (x[i] - mu) * is * Cc);
+      const float xv = x[i];
+      if (relu == 1 && !(z[zi] > 0.f)) d = 0.f;
+      if (relu == 2 && !(xv * rsc + rsf > 0.f)) d = 0.f;
+      dx[i] = A * (d - B - (xv - mu) * is * Cc);
       if (dres) dres[i] = dres_acc ? dres[i] + d : d;
     }
   }
@@ -253,11 +266,11 @@ int gca_bn_stats(const float* x, int64_t N, int64_t C, int64_t SP, float* stat_s
   if (SP % 4 == 0 && ((uintptr_t)x % 16) == 0)
     hipLaunchKernelGGL((bn_reduce_kernel<0, 4>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
                        nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
-                       stat_sum, stat_sq);
+                       stat_sum, stat_sq, nullptr, nullptr);
   else
     hipLaunchKernelGGL((bn_reduce_kernel<0, 1>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
                        nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
-                       stat_sum, stat_sq);
+                       stat_sum, stat_sq, nullptr, nullptr);
   return gca_launch_status();
 }
 
@@ -304,9 +317,11 @@ int64_t gca_bn_bwd_ws_bytes(int64_t N, int64_t C, int64_t SP) {
 int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* gamma,
                const float* save_mean, const float* save_invstd, int relu,
                int64_t N, int64_t C, int64_t SP, float* dx, float* dgamma, float* dbeta,
-               float* dres, int dres_accumulate, int64_t z_batch_stride, void* ws, void* stream) {
+               float* dres, int dres_accumulate, int64_t z_batch_stride, const float* scale, const float* shift,
+               void* ws, void* stream) {
   if (!dz_in || !x || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
-  if (relu && !z) return GCA_EINVAL;
+  if (relu < 0 || relu > 2 || (relu == 1 && !z) || (relu == 2 && (!scale || !shift))) return GCA_EINVAL;
+  if (relu != 1) z = dz_in;                 // never dereferenced; keeps the alignment test below meaningful
   if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
   const long long zs = z_batch_stride ? z_batch_stride : C * SP;
   hipStream_t st = (hipStream_t)stream;
@@ -316,10 +331,10 @@ int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* 
   float* coef = p1 + (long long)C * P;
   if ((SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x) % 16 == 0))
     hipLaunchKernelGGL((bn_reduce_kernel<1, 4>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1);
+                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1, scale, shift);
   else
     hipLaunchKernelGGL((bn_reduce_kernel<1, 1>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1);
+                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1, scale, shift);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, p0, p1, P, (double)N * (double)SP,
                      gamma, save_invstd, dgamma, dbeta, coef, (long long)C);
   const long long total = (long long)N * C * SP;
@@ -327,10 +342,10 @@ int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* 
                   (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
   if (v4)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_grid(total, 4)), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate);
+                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate, scale, shift);
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_grid(total, 1)), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate);
+                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate, scale, shift);
   return gca_launch_status();
 }
 

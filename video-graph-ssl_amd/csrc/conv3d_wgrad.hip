@@ -112,88 +112,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const unsigned a_row0 = (unsigned)(tileM * BM + (AVEC ? ga : g)) * OSP * 4u;
   const unsigned a_step = (AVEC ? 32u : 8u) * OSP * 4u;
 
-  auto load_tiles = [&](int kt) __attribute__((always_inline)) {
-    // ---- A: dY[img, m, o]
+  // The next tile's fetch is split into pieces that are issued BETWEEN the MFMA groups of the current tile (see
+  // conv3d.hip): prep = position arithmetic + window mask, then the dY loads, then the X gathers in chunks.
+  unsigned nx_abase = 0, nx_bbase = 0, nx_ilo = 0xffffffffu, nx_ihi = 0xffffffffu;
+  bool nx_av = false, nx_kv = false;
+  int nx_id0 = 0, nx_ih0 = 0, nx_iw0 = 0;
+  auto prep = [&](int kt) __attribute__((always_inline)) {
+    unsigned img4 = 0, o4 = 0;
     if (AVEC) {
       const unsigned kp = (unsigned)kt * WBK + kq * 4;          // 4 consecutive positions, same image (OSP % 4 == 0)
-      const bool kv4 = kp < p.Ktot;
-      const unsigned kc = kv4 ? kp : 0u;
-      const unsigned img = gca_fdiv(kc, p.m_osp);
-      const unsigned o = kc - img * OSP;
-      const unsigned base = (img * (unsigned)p.K * OSP + o) * 4u + a_row0;
-#pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const unsigned voff = (kv4 && 32 * i < a_rows_left) ? base + (unsigned)i * a_step : 0xffffffffu;
-        // whole-vector bit_cast: element-wise __builtin_bit_cast miscompiles to a replicated dword load (ROCm 7.2)
-        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)voff, 0, 0));
-        avec[i] = make_float4(f.x, f.y, f.z, f.w);
-      }
-      if (BVEC) {                                               // X rows for the same 4 positions
-        const unsigned od = gca_fdiv(o, p.m_ohw), r = o - od * p.m_ohw.d;
-        const int id0 = (int)od * p.sd - p.pd;
-        const unsigned bbase = (img * p.x_nstride + (unsigned)(id0 * HW) + r) * 4u;
-        const unsigned inval = kv4 ? ~tap_valid_mask<unsigned>(p, id0, 0, 0, chkD, false, false) : 0xffffffffu;
-#pragma unroll
-        for (int j = 0; j < B_PER; ++j) {
-          const int2 e = Ts[ga + 32 * j];
-          const unsigned voff = (bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)inval, e.y, 1);
-          const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0));
-          bvec[j] = make_float4(f.x, f.y, f.z, f.w);
-        }
-        return;
-      }
+      nx_av = kp < p.Ktot;
+      const unsigned kc = nx_av ? kp : 0u;
+      img4 = gca_fdiv(kc, p.m_osp);
+      o4 = kc - img4 * OSP;
+      nx_abase = (img4 * (unsigned)p.K * OSP + o4) * 4u + a_row0;
     }
-    // ---- per-lane spatial position of the B column (and of scalar A)
+    if (BVEC) {                                                 // X rows for the same 4 positions
+      const unsigned od = gca_fdiv(o4, p.m_ohw), r = o4 - od * p.m_ohw.d;
+      const int id0 = (int)od * p.sd - p.pd;
+      nx_bbase = (img4 * p.x_nstride + (unsigned)(id0 * HW) + r) * 4u;
+      nx_ilo = nx_av ? ~tap_valid_mask<unsigned>(p, id0, 0, 0, chkD, false, false) : 0xffffffffu;
+      return;
+    }
+    // per-lane spatial position of the B column (and of scalar A)
     const unsigned kp = (unsigned)kt * WBK + kl;
-    const bool kv = kp < p.Ktot;
-    const unsigned kc = kv ? kp : 0u;
+    nx_kv = kp < p.Ktot;
+    const unsigned kc = nx_kv ? kp : 0u;
     const unsigned img = gca_fdiv(kc, p.m_osp);
     const unsigned o = kc - img * OSP;
-    if (!AVEC) {
-      const unsigned base = (img * (unsigned)p.K * OSP + o) * 4u + a_row0;
-#pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const unsigned voff = (kv && 8 * i < a_rows_left) ? base + (unsigned)i * a_step : 0xffffffffu;
-        areg[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (int)voff, 0, 0));
-      }
-    }
-    // ---- B: X window element for (c, tap) = table row n'
+    if (!AVEC) { nx_av = nx_kv; nx_abase = (img * (unsigned)p.K * OSP + o) * 4u + a_row0; }
     const unsigned od = gca_fdiv(o, p.m_ohw), r = o - od * p.m_ohw.d;
     const unsigned oh = gca_fdiv(r, p.m_ow), ow = r - oh * (unsigned)p.OW;
-    const int id0 = (int)od * p.sd - p.pd, ih0 = (int)oh * p.sh - p.ph, iw0 = (int)ow * p.sw - p.pw;
-    const unsigned bbase = (img * p.x_nstride + (unsigned)(id0 * HW + ih0 * p.W + iw0)) * 4u;
-    if (FAST == 1) {
-      const unsigned inval = kv ? ~tap_valid_mask<unsigned>(p, id0, ih0, iw0, chkD, chkH, chkW) : 0xffffffffu;
+    nx_id0 = (int)od * p.sd - p.pd; nx_ih0 = (int)oh * p.sh - p.ph; nx_iw0 = (int)ow * p.sw - p.pw;
+    nx_bbase = (img * p.x_nstride + (unsigned)(nx_id0 * HW + nx_ih0 * p.W + nx_iw0)) * 4u;
+    if (FAST == 1) nx_ilo = nx_kv ? ~tap_valid_mask<unsigned>(p, nx_id0, nx_ih0, nx_iw0, chkD, chkH, chkW) : 0xffffffffu;
+    if (FAST == 2) {
+      const unsigned long long inval = nx_kv ? ~tap_valid_mask<unsigned long long>(p, nx_id0, nx_ih0, nx_iw0, chkD, chkH, chkW) : ~0ull;
+      nx_ilo = (unsigned)inval; nx_ihi = (unsigned)(inval >> 32);
+    }
+  };
+  auto issue_a = [&]() __attribute__((always_inline)) {          // dY[img, m, o]
 #pragma unroll
-      for (int j = 0; j < B_PER; ++j) {
-        const int2 e = Ts[g + 8 * j];                                     // x: byte offset, y: tap id in the low bits
-        const unsigned voff = (bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)inval, e.y, 1);
-        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
-      }
-    } else if (FAST == 2) {
-      const unsigned long long inval = kv ? ~tap_valid_mask<unsigned long long>(p, id0, ih0, iw0, chkD, chkH, chkW) : ~0ull;
-      const unsigned ilo = (unsigned)inval, ihi = (unsigned)(inval >> 32);
-#pragma unroll
-      for (int j = 0; j < B_PER; ++j) {
-        const int2 e = Ts[g + 8 * j];
-        const unsigned m = (e.y & 32) ? ihi : ilo;
-        const unsigned voff = (bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)m, e.y, 1);
-        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < B_PER; ++j) {
-        const int2 e = Ts[g + 8 * j];
-        int off, dd, dh, dw, rvalid;
-        decode_row(e, off, dd, dh, dw, rvalid);
-        bool ok = kv & (rvalid != 0);
-        if (chkD) ok = ok & ((unsigned)(id0 + dd) < (unsigned)p.D);
-        if (chkH) ok = ok & ((unsigned)(ih0 + dh) < (unsigned)p.H);
-        if (chkW) ok = ok & ((unsigned)(iw0 + dw) < (unsigned)p.W);
-        const unsigned voff = (bbase + (unsigned)off) | (ok ? 0u : 0xffffffffu);
-        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)voff, 0, 0));
+    for (int i = 0; i < A_PER; ++i) {
+      const unsigned voff = (nx_av && (AVEC ? 32 : 8) * i < a_rows_left) ? nx_abase + (unsigned)i * a_step : 0xffffffffu;
+      if (AVEC) {
+        // whole-vector bit_cast: element-wise __builtin_bit_cast miscompiles to a replicated dword load (ROCm 7.2)
+        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)voff, 0, 0));
+        avec[AVEC ? i : 0] = make_float4(f.x, f.y, f.z, f.w);
+      } else {
+        areg[AVEC ? 0 : i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (int)voff, 0, 0));
       }
     }
+  };
+  auto issue_b = [&](int j) __attribute__((always_inline)) {     // X window element(s) of table row n' (j: constant)
+    if (BVEC) {
+      const int2 e = Ts[ga + 32 * j];                            // x: byte offset, y: tap id in the low bits
+      const unsigned voff = (nx_bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)nx_ilo, e.y, 1);
+      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0));
+      bvec[BVEC ? j : 0] = make_float4(f.x, f.y, f.z, f.w);
+      return;
+    }
+    const int2 e = Ts[g + 8 * j];
+    unsigned inv;
+    if (FAST == 1) inv = (unsigned)__builtin_amdgcn_sbfe((int)nx_ilo, e.y, 1);
+    else if (FAST == 2) {
+      const unsigned hsel = (unsigned)-((e.y >> 5) & 1);
+      inv = (unsigned)__builtin_amdgcn_sbfe((int)(nx_ilo ^ ((nx_ilo ^ nx_ihi) & hsel)), e.y, 1);
+    } else {
+      int off, dd, dh, dw, rvalid;
+      decode_row(e, off, dd, dh, dw, rvalid);
+      bool ok = nx_kv & (rvalid != 0);
+      if (chkD) ok = ok & ((unsigned)(nx_id0 + dd) < (unsigned)p.D);
+      if (chkH) ok = ok & ((unsigned)(nx_ih0 + dh) < (unsigned)p.H);
+      if (chkW) ok = ok & ((unsigned)(nx_iw0 + dw) < (unsigned)p.W);
+      inv = ok ? 0u : 0xffffffffu;
+    }
+    breg[BVEC ? 0 : j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)((nx_bbase + (unsigned)e.x) | inv), 0, 0));
+  };
+  constexpr int G = (WBK / 8) * TM * TN;                         // MFMA groups (4 dependent MFMAs each) per tile
+  constexpr int GSPAN = G > 2 ? G - 2 : 1;
+  constexpr int GCHUNK = (B_PER + GSPAN - 1) / GSPAN;
+  auto issue_piece = [&](int gi, int kt) __attribute__((always_inline)) {
+    if (gi == 0) { prep(kt); issue_a(); }
+    else if (gi <= GSPAN) {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j)
+        if (j >= (gi - 1) * GCHUNK && j < gi * GCHUNK) issue_b(j);
+    }
+  };
+  auto load_tiles = [&](int kt) __attribute__((always_inline)) {   // everything at once (prologue)
+    prep(kt);
+    issue_a();
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) issue_b(j);
   };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
     if (AVEC) {
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   __syncthreads();
   for (int kt = kt0; kt < kt1; ++kt) {
     const int buf = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tiles(kt + 1);            // in flight during the MFMA phase below
+    const bool more = kt + 1 < kt1;
 #pragma unroll
     for (int t = 0; t < WBK / 8; ++t) {
       float4 af[TM], bf[TN];
@@ -235,9 +246,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
+          __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (kt + 1 < kt1) store_tiles(buf ^ 1);
+    if (more) store_tiles(buf ^ 1);
     __syncthreads();
   }
 

@@ -234,8 +234,11 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
             dres = racc = None
             if residual is not None and residual.needs_grad:
                 dres, racc = residual.grad_buffer()
-            dy = ops.bn_bwd(zv.grad, z, y, bn.weight.data, mean, invstd, relu, N, K, SP,
-                            _grad_of(bn.weight), _grad_of(bn.bias), dres, bool(racc))
+            # ReLU mask: with no residual in front of the ReLU it is recomputed from y (the forward's own scale/shift),
+            # so z is not streamed again; with a residual the saved output is the only record
+            mode = (2 if residual is None else 1) if relu else 0
+            dy = ops.bn_bwd(zv.grad, z, y, bn.weight.data, mean, invstd, mode, N, K, SP,
+                            _grad_of(bn.weight), _grad_of(bn.bias), dres, bool(racc), scale, shift)
             if DEBUG_GRADS is not None:          # diagnostics only: gradient wrt the conv output, per BN module
                 DEBUG_GRADS[id(bn)] = (zv.grad.clone(), dy.clone())
             zv.grad = None
@@ -308,8 +311,8 @@ def f_bn1d_act(tape, bn, xv, relu):
     def back():
         if mean is None:
             raise NotImplementedError('backward through eval-mode BatchNorm1d')
-        dx = ops.bn_bwd(zv.grad, z, x, bn.weight.data, mean, invstd, relu, b, Cc, 1,
-                        _grad_of(bn.weight), _grad_of(bn.bias))
+        dx = ops.bn_bwd(zv.grad, z, x, bn.weight.data, mean, invstd, 2 if relu else 0, b, Cc, 1,
+                        _grad_of(bn.weight), _grad_of(bn.bias), None, False, scale, shift)
         zv.grad = None
         if xv.needs_grad:
             xv.add_grad(dx)

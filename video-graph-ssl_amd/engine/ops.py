@@ -349,11 +349,14 @@ def bn_apply(x, scale, shift, residual, relu, N, Cc, SP, out=None):
     return z
 
 
-def bn_bwd(dz, z, x, gamma, mean, invstd, relu, N, Cc, SP, dgamma, dbeta, dres=None, dres_accumulate=False):
+def bn_bwd(dz, z, x, gamma, mean, invstd, relu, N, Cc, SP, dgamma, dbeta, dres=None, dres_accumulate=False,
+           scale=None, shift=None):
+    """relu: False/0 none, True/1 mask from z, 2 mask recomputed from x with the forward's (scale, shift)."""
     dx = torch.empty_like(x)
     ws = WS.get(H.lib.gca_bn_bwd_ws_bytes(N, Cc, SP), x.device)
-    H.call('gca_bn_bwd', ptr(dz), ptr(z), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu), N, Cc, SP, ptr(dx),
-           ptr(dgamma), ptr(dbeta), ptr(dres), int(dres_accumulate), _slice_stride(dz, Cc, SP), ptr(ws), stream())
+    H.call('gca_bn_bwd', ptr(dz), ptr(z) if int(relu) == 1 else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu),
+           N, Cc, SP, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dres), int(dres_accumulate), _slice_stride(dz, Cc, SP),
+           ptr(scale), ptr(shift), ptr(ws), stream())
     return dx
 
 
