@@ -161,7 +161,10 @@ typedef struct {
   int32_t kd, kh, kw, sd, sh, sw, pd, ph, pw;
   int32_t OD, OH, OW;
 } gca_pool_geom;
-int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, void* stream);
+/* scale/shift (both or neither): pool relu(x*scale[c] + shift[c]) instead of x -- the BatchNorm+ReLU in front of
+ * the pool (resnet2p1d.py:252-255 conv1_t -> bn1_t -> relu -> maxpool) evaluated on the fly. */
+int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, const float* scale,
+                      const float* shift, void* stream);
 int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* argmax, float* dx,
                       int accumulate, void* stream);
 /* y[n,c] = sum_{d,h,w} wt[d] * x[n,c,d,h,w] * norm   (wt == NULL -> all ones) */

@@ -467,3 +467,17 @@ def test_batched_weight_pack_equals_per_layer_pack(pkg, ops):
     assert torch.equal(net[0].packed(net[0]._pack_plan[0], 0), refs[0])
     packer.release()
     assert torch.equal(net[0].packed(net[0]._pack_plan[0], 0), refs[0] * 2.0)
+
+
+def test_maxpool_with_fused_bn_relu_producer(ops):
+    """gca_maxpool3d_fwd(scale, shift) == maxpool(bn_apply(x, relu)) bit for bit, argmax included
+    (the stem of resnet2p1d.py:252-255 / resnet.py:176-179 without materialising the normalised tensor)."""
+    torch.manual_seed(9)
+    x = torch.randn(2, 6, 5, 10, 12, device=DEV)
+    sc, sh = torch.randn(6, device=DEV), torch.randn(6, device=DEV)
+    z = ops.bn_apply(x, sc, sh, None, True, 2, 6, 5 * 10 * 12)
+    for k, s, p in (((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((1, 3, 3), (1, 2, 2), (0, 1, 1)), ((2, 3, 1), (1, 2, 1), (1, 0, 0))):
+        plan = ops.pool_plan(tuple(x.shape), k, s, p)
+        y0, a0 = ops.maxpool_fwd(plan, z)
+        y1, a1 = ops.maxpool_fwd(plan, x, True, sc, sh)
+        assert torch.equal(y0, y1) and torch.equal(a0, a1)

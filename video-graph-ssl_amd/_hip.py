@@ -65,7 +65,7 @@ SIGNATURES = {
     'gca_bn_bwd_ws_bytes': (c_i64, [c_i64, c_i64, c_i64]),
     'gca_bn_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
                            c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
-    'gca_maxpool3d_fwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_vp]),
+    'gca_maxpool3d_fwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'gca_maxpool3d_bwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'gca_wavgpool_fwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_vp]),
     'gca_wavgpool_bwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_vp]),

@@ -9,6 +9,7 @@ struct PoolMagic {
   gca_magic osp, ohw, ow;       // output decomposition
   gca_magic sp, hw, w;          // input decomposition
   gca_magic sd, sh, sw;         // strides
+  gca_magic c;                  // channels (plane -> channel for the fused BN+ReLU producer)
 };
 
 // One thread per output element.  Tie break = first maximum in (d,h,w) scan order and NaN propagates, exactly
@@ -17,10 +18,16 @@ struct PoolMagic {
 template <int KD, int KH, int KW>
 __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ x,
                                                             float* __restrict__ y, int* __restrict__ argmax,
-                                                            unsigned total) {
+                                                            unsigned total, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
   const unsigned plane = gca_fdiv(i, q.osp), o = i - plane * q.osp.d;
+  // optional fused producer: the pooled tensor is relu(x*scale[c] + shift[c]) (BatchNorm + ReLU of the conv output x),
+  // evaluated on the fly exactly as bn_apply would, so that tensor is never written or read
+  float sc = 1.f, sf = 0.f;
+  if (scale) { const unsigned c = plane - gca_fdiv(plane, q.c) * q.c.d; sc = scale[c]; sf = shift[c]; }
+#define GCA_POOL_VAL(v) (scale ? fmaxf((v) * sc + sf, 0.f) : (v))
   const int od = (int)gca_fdiv(o, q.ohw), r = (int)(o - (unsigned)od * q.ohw.d);
   const int oh = (int)gca_fdiv((unsigned)r, q.ow), ow = r - oh * g.OW;
   const int d0 = od * g.sd - g.pd, h0 = oh * g.sh - g.ph, w0 = ow * g.sw - g.pw;
@@ -37,7 +44,7 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
           const int d = d0 + a, h = h0 + b, w = w0 + c;
           const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
           const int idx = (d * g.H + h) * g.W + w;
-          const float v = xp[ok ? idx : bi];
+          const float v = GCA_POOL_VAL(xp[ok ? idx : bi]);
           if (ok && (v > best || isnan(v))) { best = v; bi = idx; }
         }
   } else {
@@ -46,10 +53,11 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
       for (int h = max(h0, 0); h < h1; ++h)
         for (int w = max(w0, 0); w < w1; ++w) {
           const int idx = (d * g.H + h) * g.W + w;
-          const float v = xp[idx];
+          const float v = GCA_POOL_VAL(xp[idx]);
           if (v > best || isnan(v)) { best = v; bi = idx; }
         }
   }
+#undef GCA_POOL_VAL
   y[i] = best;
   if (argmax) argmax[i] = bi;
 }
@@ -154,19 +162,21 @@ static PoolMagic pool_magic(const gca_pool_geom* g) {
   q.ow = gca_make_magic((unsigned)g->OW);
   q.sp = gca_make_magic((unsigned)(g->D * g->H * g->W)); q.hw = gca_make_magic((unsigned)(g->H * g->W));
   q.w = gca_make_magic((unsigned)g->W);
+  q.c = gca_make_magic((unsigned)g->C);
   q.sd = gca_make_magic((unsigned)g->sd); q.sh = gca_make_magic((unsigned)g->sh); q.sw = gca_make_magic((unsigned)g->sw);
   return q;
 }
 
-int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, void* stream) {
-  if (!pool_ok(g) || !x || !y) return GCA_EINVAL;
+int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, const float* scale,
+                      const float* shift, void* stream) {
+  if (!pool_ok(g) || !x || !y || ((scale == nullptr) != (shift == nullptr))) return GCA_EINVAL;
   const long long total = (long long)g->N * g->C * g->OD * g->OH * g->OW;
   if (total >= (1LL << 31) || (long long)g->D * g->H * g->W >= (1LL << 31)) return GCA_EINVAL;
   const PoolMagic q = pool_magic(g);
   const dim3 grid((unsigned)gca_ceil_div(total, 256));
   hipStream_t st = (hipStream_t)stream;
 #define GCA_POOL_FWD(KD, KH, KW) \
-  hipLaunchKernelGGL((maxpool3d_fwd_kernel<KD, KH, KW>), grid, dim3(256), 0, st, *g, q, x, y, argmax, (unsigned)total)
+  hipLaunchKernelGGL((maxpool3d_fwd_kernel<KD, KH, KW>), grid, dim3(256), 0, st, *g, q, x, y, argmax, (unsigned)total, scale, shift)
   if (g->kd == 3 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(3, 3, 3);
   else if (g->kd == 1 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(1, 3, 3);
   else if (g->kd == 2 && g->kh == 2 && g->kw == 2) GCA_POOL_FWD(2, 2, 2);

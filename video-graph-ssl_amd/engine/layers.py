@@ -332,6 +332,43 @@ def f_relu(tape, xv):
     return yv
 
 
+def f_conv_bn_relu_maxpool(tape, conv, bn, pool, xv):
+    """maxpool(relu(BN(conv(x)))) with the BN+ReLU evaluated inside the pooling kernel: the normalised tensor (the
+    largest activation of the R(2+1)D / 3D-ResNet stems, resnet2p1d.py:252-255, resnet.py:176-179) is never written.
+    Backward: pool gather -> BN backward with the ReLU mask recomputed from the conv output -> wgrad / dgrad."""
+    x = xv.t
+    plan = conv.plan(x)
+    N, K, OD, OH, OW = plan.out_shape
+    SP = OD * OH * OW
+    wp = conv.packed(plan, 0)
+    if bn.training:
+        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True)
+        mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
+    else:
+        y = ops.conv_fwd(plan, x, wp, None)
+        mean = invstd = None
+        scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
+    pplan = ops.pool_plan(tuple(y.shape), pool.kernel_size, pool.stride, pool.padding)
+    p, am = ops.maxpool_fwd(pplan, y, want_argmax=tape.recording, scale=scale, shift=shift)
+    pv = Var(p, tape.recording)
+    if tape.recording:
+        if mean is None:
+            raise NotImplementedError('backward through eval-mode BatchNorm is not on the pre-training path')
+
+        def back():
+            dz = ops.maxpool_bwd(pplan, pv.grad, am)
+            pv.grad = None
+            dy = ops.bn_bwd(dz, None, y, bn.weight.data, mean, invstd, 2, N, K, SP, _grad_of(bn.weight), _grad_of(bn.bias),
+                            None, False, scale, shift)
+            del dz
+            ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
+            if xv.needs_grad:
+                buf, acc = xv.grad_buffer()
+                ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
+        tape.record(back)
+    return pv
+
+
 def f_maxpool(tape, pool, xv):
     x = xv.t
     plan = ops.pool_plan(tuple(x.shape), pool.kernel_size, pool.stride, pool.padding)

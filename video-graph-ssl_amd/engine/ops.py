@@ -378,10 +378,11 @@ def pool_plan(x_shape, k, s, p):
     return PoolPlan(x_shape, k, s, p)
 
 
-def maxpool_fwd(plan, x, want_argmax=True):
+def maxpool_fwd(plan, x, want_argmax=True, scale=None, shift=None):
+    """scale/shift: pool relu(x*scale[c]+shift[c]) (the BatchNorm+ReLU in front of the pool) without materialising it."""
     y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
     am = torch.empty(plan.out_shape, dtype=torch.int32, device=x.device) if want_argmax else None
-    H.call('gca_maxpool3d_fwd', plan.gp, ptr(x), ptr(y), ptr(am), stream())
+    H.call('gca_maxpool3d_fwd', plan.gp, ptr(x), ptr(y), ptr(am), ptr(scale), ptr(shift), stream())
     return y, am
 
 

@@ -100,8 +100,7 @@ class ResNet(nn.Module):
         return nn.Sequential(*mods)
 
     def fwd(self, tape, xv):
-        x = L.f_conv_bn_act(tape, self.conv1, self.bn1, xv)
-        x = L.f_maxpool(tape, self.maxpool, x)
+        x = L.f_conv_bn_relu_maxpool(tape, self.conv1, self.bn1, self.maxpool, xv)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = L.f_seq(tape, stage, x)
         if tuple(x.t.shape[2:]) != self.pool_window:

@@ -134,9 +134,10 @@ class ResNet(nn.Module):
 
     def fwd(self, tape, xv):
         x = L.f_conv_bn_act(tape, self.conv1_s, self.bn1_s, xv)
-        x = L.f_conv_bn_act(tape, self.conv1_t, self.bn1_t, x)
-        if not self.no_max_pool:
-            x = L.f_maxpool(tape, self.maxpool, x)
+        if not self.no_max_pool:          # conv1_t -> bn1_t -> relu -> maxpool: BN+ReLU evaluated inside the pool kernel
+            x = L.f_conv_bn_relu_maxpool(tape, self.conv1_t, self.bn1_t, self.maxpool, x)
+        else:
+            x = L.f_conv_bn_act(tape, self.conv1_t, self.bn1_t, x)
         for stage in (self.layer1, self.layer2, self.layer3, self.layer4):
             x = L.f_seq(tape, stage, x)
         x = L.f_wavgpool(tape, x)              # global mean == AdaptiveAvgPool3d(1) + flatten (:260-262)
