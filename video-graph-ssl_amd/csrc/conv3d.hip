@@ -339,9 +339,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     }
   }
   if (psum) {
-    // per-channel partial sum / sum of squares over this wave's columns (invalid columns hold 0): DPP adds over
-    // the 32 lanes of each wave half; the totals land in lanes 16..31 / 48..63.
-    const int part = tileN * WN + wn;
+    // per-channel partial sum / sum of squares of this TILE (invalid columns hold 0): DPP adds over the 32 lanes of
+    // each wave half (totals land in lanes 16..31 / 48..63), then the four waves' totals are combined through LDS
+    // (the operand tiles are dead by now) so that BatchNorm's finalize reads one partial per tile, not four.
+    float* red = &Bs[0][0][0];                                // [WN][BM][2] floats  (<= 4*160*2 < one B buffer)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -351,13 +352,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
         for (int j = 0; j < TN; ++j) { const float v = acc[i][j][r]; s += v; q += v * v; }
         s = half_wave_sum_hi(s);
         q = half_wave_sum_hi(q);
-        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
-        if (ll == 31 && ro < rows_left) {
-          const long long m = mbase + ro + 4 * lh;
-          psum[m * p.P + part] = s;
-          psq[m * p.P + part] = q;
-        }
+        const int ro = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (ll == 31) { red[(wn * BM + ro) * 2] = s; red[(wn * BM + ro) * 2 + 1] = q; }
       }
+    }
+    __syncthreads();
+    if (tid < BM && mbase + tid < p.DK) {
+      const float s = red[tid * 2] + red[(BM + tid) * 2] + red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2];
+      const float q = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1] + red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1];
+      const long long m = mbase + tid;
+      psum[m * p.P + tileN] = s;
+      psq[m * p.P + tileN] = q;
     }
   }
 }
@@ -645,7 +650,7 @@ void launch_tm(const IgemmCfg& c, int fast, dim3 grid, hipStream_t st, const flo
 
 inline int stat_parts(const IgemmCfg& c, long long Ntot) {
   if (c.splits > 1) return (int)gca_ceil_div(Ntot, FINISH_CHUNK);
-  return (int)gca_ceil_div(Ntot, c.bn) * 4;
+  return (int)gca_ceil_div(Ntot, c.bn);
 }
 
 int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack, const int2* table, const float* bias,
