@@ -27,6 +27,7 @@
 //
 // Reference call sites replaced: every nn.Conv3d / nn.Linear on the path (see include/gca_hip.h).
 #include <cstring>
+#include <type_traits>
 #include "conv_common.h"
 
 #include <cstdlib>
@@ -247,9 +248,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     store_tiles(0);
   }
   __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
+  // One k-tile: 2 x TM x TN groups of four dependent MFMAs with the pieces of the next tile's fetch in between.
+  // BUF (LDS buffer) and MORE (is there a next tile) are compile-time, so the steady-state loop below carries no
+  // buffer arithmetic and no per-group branches; the last tile(s) are peeled.
+  auto tile = [&](auto BUF, auto MORE, int kt_next) __attribute__((always_inline)) {
+    constexpr int buf = decltype(BUF)::value;
+    constexpr bool more = decltype(MORE)::value;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float4 af[TM], bf[TN];
@@ -265,13 +269,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece((t * TM + i) * TN + j, kt_next);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
     }
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  if (TM <= 2 && !VEC) {
+    // small tiles: the loop is unrolled by two (buffers 0 / 1) and the tail peeled -- the per-tile scalar
+    // bookkeeping is a visible share of an iteration that holds only 8-16 MFMAs (measured +2..+8 % here, but a
+    // loss for the tall / 256-column tiles, whose bodies are already long: they keep the rolled loop below)
+    int kt = kt0;
+    for (; kt + 2 < kt1; kt += 2) {
+      tile(B0{}, std::true_type{}, kt + 1);
+      tile(B1{}, std::true_type{}, kt + 2);
+    }
+    if (kt + 1 < kt1) {
+      tile(B0{}, std::true_type{}, kt + 1);
+      tile(B1{}, std::false_type{}, 0);
+    } else if (kt < kt1) {
+      tile(B0{}, std::false_type{}, 0);
+    }
+  } else {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        float4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][i * 32 + ll][8 * t + 4 * lh]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][8 * t + 4 * lh]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
