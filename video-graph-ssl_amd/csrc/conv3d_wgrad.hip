@@ -9,6 +9,7 @@
 // are read as float4 when the output plane size allows it.  X is gathered through a buffer resource (an
 // out-of-window tap is an out-of-range offset and reads 0 in hardware).  K is split across workgroups into
 // fp32 partial slabs that are summed in a fixed order (deterministic).
+#include <type_traits>
 #include "conv_common.h"
 
 using namespace gca_conv;
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     store_tiles(0);
   }
   __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    const bool more = kt + 1 < kt1;
+  auto tile = [&](auto BUF, auto MORE, int kt_next) __attribute__((always_inline)) {
+    constexpr int buf = decltype(BUF)::value;
+    constexpr bool more = decltype(MORE)::value;
 #pragma unroll
     for (int t = 0; t < WBK / 8; ++t) {
       float4 af[TM], bf[TN];
@@ -246,13 +247,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
-          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece((t * TM + i) * TN + j, kt_next);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
     }
     if (more) store_tiles(buf ^ 1);
     __syncthreads();
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  if (TM * TN <= 2) {       // small tiles: unrolled by two with compile-time buffers, tail peeled (as in conv3d.hip)
+    int kt = kt0;
+    for (; kt + 2 < kt1; kt += 2) {
+      tile(B0{}, std::true_type{}, kt + 1);
+      tile(B1{}, std::true_type{}, kt + 2);
+    }
+    if (kt + 1 < kt1) {
+      tile(B0{}, std::true_type{}, kt + 1);
+      tile(B1{}, std::false_type{}, 0);
+    } else if (kt < kt1) {
+      tile(B0{}, std::false_type{}, 0);
+    }
+  } else {
+  for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+#pragma unroll
+      for (int t = 0; t < WBK / 8; ++t) {
+        float4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(&As[buf][wm * (TM * 32) + i * 32 + ll][8 * t + 4 * lh]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][8 * t + 4 * lh]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+
   }
 
   // ---- epilogue: partial tile -> slab[split][m][n] through a buffer resource (one 32-bit offset per column
