@@ -324,15 +324,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   }
 }
 
-// dw[i] (+)= sum_s slab[s][i]   (fixed order: deterministic)
-__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
-                                     int splits, int accumulate) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// dw[i] (+)= sum_s slab[s][i]   (fixed order: deterministic).  A block owns 64 consecutive outputs; its four waves
+// each sum every fourth slab (short dependent chains, 4x the workgroups of a thread-per-output layout) and the four
+// partial sums are combined in a fixed order through LDS.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw,
+                                                            long long n, int splits, int accumulate) {
+  __shared__ float sh[4][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + x;
   float s = 0.f;
-  for (int k = 0; k < splits; ++k) s += slab[(long long)k * n + i];
-  if (accumulate) s += dw[i];
-  dw[i] = s;
+  if (i < n)
+    for (int k = y; k < splits; k += 4) s += slab[(long long)k * n + i];
+  sh[y][x] = s;
+  __syncthreads();
+  if (y == 0 && i < n) {
+    float t = (sh[0][x] + sh[1][x]) + (sh[2][x] + sh[3][x]);
+    if (accumulate) t += dw[i];
+    dw[i] = t;
+  }
 }
 
 __global__ void bias_grad_kernel(const float* __restrict__ dy, long long N, long long K, long long SP,
@@ -494,7 +503,7 @@ int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, cons
   rc = gca_launch_status();
   if (rc) return rc;
   const long long n = (long long)g->K * p.Kred;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 256)), dim3(256), 0, st, slab, dw, n,
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 64)), dim3(256), 0, st, slab, dw, n,
                      p.splits, accumulate ? 1 : 0);
   return gca_launch_status();
 }
