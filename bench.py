@@ -126,9 +126,10 @@ def kernel_timing(pkg, trainer, args):
             layers.append((Lin(m.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), m.weight), (b, m.in_features, 1, 1, 1), 0))
     sym = {}
 
-    def add(name, ms, flops, times):
+    def add(name, ms, flops, times, launches=1):
+        # `launches`: kernel launches behind one call (a strided dgrad is one launch per stride-residue class)
         e = sym.setdefault(name, [0.0, 0.0, 0])
-        e[0] += ms * times; e[1] += flops * times; e[2] += times
+        e[0] += ms * times; e[1] += flops * times; e[2] += times * launches
 
     dev = torch.device('cuda', torch.cuda.current_device())
     for i, (m, shp, xs) in enumerate(layers):
@@ -150,7 +151,7 @@ def kernel_timing(pkg, trainer, args):
             # (the head's first Linear does: its input is the encoder feature)
             t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
             c1 = plan.cfg(1)
-            add(_sym(c1), t, flops, 1)
+            add(_sym(c1), t, flops, 1, max(1, c1[3] & 255))
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         cw = plan.cfg(2)
         add('conv_wgrad_kernel<%dx%d>' % (cw[0], cw[1]), t, flops, 1)
