@@ -47,7 +47,10 @@ class _Graphed(object):
                 return self.fn()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):        # records the launches, does not execute them
+            # with a process group alive, its watchdog thread polls events while we capture: only THIS thread's
+            # calls must be checked against the capture (the default "global" mode would fail the capture)
+            mode = 'thread_local' if torch.distributed.is_available() and torch.distributed.is_initialized() else 'global'
+            with torch.cuda.graph(g, capture_error_mode=mode):        # records the launches, does not execute them
                 self.fn()
             self.graph = g
         self.graph.replay()
