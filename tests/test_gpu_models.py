@@ -284,3 +284,34 @@ def test_simsiam_trainer_steps_vs_oracle(pkg, use_graph):
     # fp64 like any fp32 path, lands on the other side, and one flipped mask at the top of this 2048-element layer
     # moves every gradient below it by a few per cent.  A kernel bug would show on every step, a flip on one.
     assert sorted(medians)[2] < 2e-4 and max(medians) < 1e-1, medians
+
+
+def test_checkpoint_resume_is_exact(pkg):
+    """MoCoTrainer.state_dict() keeps the reference's checkpoint keys (tools/...dis.py:274-286; the optimizer entry is
+    torch.optim.SGD's own format) plus the queue pointer; a fresh trainer that loads it continues bit-identically."""
+    parity.register_tiny(pkg)
+    cfg = parity.make_cfg(pkg, 'R2P1D10T', 'moco', 32, 20, 8)
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.randn(8, 6, 8, 48, 48, generator=gen).to(DEV) for _ in range(3)]
+    a = pkg.MoCoTrainer(cfg, DEV, use_graph=False, seed=5)
+    a.train_step(xs[0]); a.train_step(xs[1])
+    sd = a.state_dict(epoch=7)
+    assert set(sd) >= {'epoch', 'state_dict', 'optimizer', 'contrast', 'model_ema'} and sd['queue_index'] == 16
+    assert set(sd['optimizer']) == {'state', 'param_groups'} and sd['optimizer']['param_groups'][0]['params'] == [0]
+    # the optimizer entry loads into a real torch.optim.SGD built the reference's way (one group per parameter)
+    ref_opt = torch.optim.SGD([{'params': [torch.nn.Parameter(p.detach().clone().cpu())]} for p in a.model.parameters()],
+                              lr=0.1, momentum=0.9)
+    ref_opt.load_state_dict({'state': {i: {'momentum_buffer': v['momentum_buffer'].cpu()} for i, v in sd['optimizer']['state'].items()},
+                             'param_groups': [dict({k: v for k, v in g.items() if k in ref_opt.param_groups[0]}, params=g['params'])
+                                              for g in sd['optimizer']['param_groups']]})
+    import io
+    buf = io.BytesIO()
+    torch.save(sd, buf)                               # round trip through the file format
+    sd2 = torch.load(io.BytesIO(buf.getvalue()), map_location='cpu', weights_only=False)
+    b = pkg.MoCoTrainer(cfg, DEV, use_graph=False, seed=99)
+    assert b.load_state_dict(sd2) == 7
+    oa, ob = a.train_step(xs[2]), b.train_step(xs[2])
+    assert torch.equal(oa['loss'], ob['loss']) and torch.equal(oa['logits'], ob['logits'])
+    for (n, p), (_, q) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.equal(p, q), n
+    assert torch.equal(a.contrast.memory, b.contrast.memory) and int(a.ptr_dev) == int(b.ptr_dev) == 4

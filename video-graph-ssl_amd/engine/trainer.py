@@ -198,7 +198,19 @@ class MoCoTrainer(object):
         """Checkpoint dict with the reference's keys (tools/...dis.py:274-286) + the queue pointer."""
         return {'epoch': epoch, 'state_dict': self.model.state_dict(), 'optimizer': self.optimizer.state_dict(),
                 'contrast': self.contrast.state_dict(), 'model_ema': self.model_ema.state_dict(),
-                'queue_index': int(self.contrast.index)}
+                'queue_index': int(self.contrast.index), 'step_count': int(self.step_count)}
+
+    def load_state_dict(self, sd):
+        """Resume from state_dict() -- or from a reference checkpoint, which lacks `queue_index` / `step_count`
+        (the reference restarts the queue pointer at 0 on resume; so do we for such a file)."""
+        self.model.load_state_dict(sd['state_dict'])
+        self.model_ema.load_state_dict(sd['model_ema'])
+        self.optimizer.load_state_dict(sd['optimizer'])
+        self.contrast.load_state_dict(sd['contrast'])
+        self.contrast.index = int(sd.get('queue_index', 0)) % self.K
+        self.ptr_dev.fill_(self.contrast.index)
+        self.step_count = int(sd.get('step_count', 0))
+        return int(sd.get('epoch', 0))
 
 
 class SimSiamTrainer(object):

@@ -48,13 +48,29 @@ class HipSGD(object):
                      self.momentum, self.nesterov)
 
     def state_dict(self):
-        return {'momentum_buffer': self.buf, 'param_groups': [{k: v for k, v in g.items() if k != 'params'}
-                                                              for g in self.param_groups]}
+        """torch.optim.SGD's wire format (what the reference checkpoints hold, tools/...dis.py:274-286): per-parameter
+        `momentum_buffer`s keyed by parameter index, one param group per parameter.  The buffers are copies."""
+        a = self.arena
+        state = {i: {'momentum_buffer': self.buf[o:o + n].view(p.shape).clone()}
+                 for i, (o, n, p) in enumerate(zip(a.offsets, a.sizes, a.params))}
+        groups = [dict({k: v for k, v in g.items() if k != 'params'}, params=[i]) for i, g in enumerate(self.param_groups)]
+        return {'state': state, 'param_groups': groups}
 
     def load_state_dict(self, sd):
-        self.buf.copy_(sd['momentum_buffer'])
-        for g, s in zip(self.param_groups, sd['param_groups']):
-            g.update(s)
+        a = self.arena
+        if 'momentum_buffer' in sd:                       # flat layout written by earlier builds of this package
+            self.buf.copy_(sd['momentum_buffer'])
+        else:
+            self.buf.zero_()
+            for i, (o, n) in enumerate(zip(a.offsets, a.sizes)):
+                st = sd['state'].get(i, sd['state'].get(str(i)))
+                if st is not None and st.get('momentum_buffer') is not None:
+                    self.buf[o:o + n].copy_(st['momentum_buffer'].reshape(-1))
+        if len(sd['param_groups']) != len(self.param_groups):
+            raise ValueError('optimizer state has %d param groups, this model needs %d'
+                             % (len(sd['param_groups']), len(self.param_groups)))
+        for g, s_ in zip(self.param_groups, sd['param_groups']):
+            g.update({k: v for k, v in s_.items() if k != 'params'})
         self._uploaded = None
 
 
