@@ -65,10 +65,10 @@ def _simulate(pkg, world, steps, init, mem0, w):
     return reps, trace
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_two_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, use_graph):
+@pytest.mark.parametrize('world,use_graph', [(2, False), (2, True), (3, True)])
+def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph):
     import dist_worker as w
-    world, steps = 2, 4
+    steps = 4
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0')
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
@@ -88,7 +88,9 @@ def test_two_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, use_graph):
         for r in range(world):
             for key in ('loss', 'logits', 'q'):
                 err = parity.rel(torch.from_numpy(outs[r]['%s%d' % (key, s)]), trace[s][r][key])
-                assert err < 1e-3, (s, r, key, err)
+                # steps 0-1 run on (nearly) identical weights: the 1e-3 bar.  Later steps are NOT teacher-forced, they carry
+                # the ReLU-boundary gradient flips of the earlier updates (parity.py), so their bar is looser.
+                assert err < (1e-3 if s < 2 else 3e-3), (s, r, key, err)
     for r in range(world):
         model, ema, contrast, _ = reps[r]
         assert parity.rel(torch.from_numpy(outs[r]['mem']), contrast.memory) < 1e-3
@@ -105,5 +107,5 @@ def test_two_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, use_graph):
     # replicas stay bit-identical in their parameters (one all-reduce, same update)
     for k in outs[0].files:
         if k.startswith('final/') and 'running' not in k and 'num_batches' not in k:
-            assert np.array_equal(outs[0][k], outs[1][k]), k
-    assert np.array_equal(outs[0]['mem'], outs[1]['mem'])
+            assert all(np.array_equal(outs[0][k], outs[r][k]) for r in range(1, world)), k
+    assert all(np.array_equal(outs[0]['mem'], outs[r]['mem']) for r in range(1, world))
