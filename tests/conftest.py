@@ -2,6 +2,11 @@ import importlib
 import os
 import sys
 
+# Launch shapes: the measured autotuner picks whatever is fastest on the day, i.e. a timing-dependent summation
+# order.  The suite runs on the deterministic heuristic shapes instead (every tile shape is forced explicitly by the
+# launch-configuration tests, and the tuner itself by test_autotuner_pins_a_valid_configuration).
+os.environ.setdefault('GCA_AUTOTUNE', '0')
+
 import numpy as np
 import pytest
 import torch

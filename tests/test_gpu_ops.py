@@ -481,3 +481,26 @@ def test_maxpool_with_fused_bn_relu_producer(ops):
         y0, a0 = ops.maxpool_fwd(plan, z)
         y1, a1 = ops.maxpool_fwd(plan, x, True, sc, sh)
         assert torch.equal(y0, y1) and torch.equal(a0, a1)
+
+
+def test_autotuner_pins_a_valid_configuration(ops):
+    """ConvPlan.tune measures the candidate launch shapes of each pass on the real operands and pins one through
+    gca_conv_geom.tune_* (the role cudnn.benchmark plays in the reference); results must not change."""
+    torch.manual_seed(6)
+    shape, K, k, s, p = (4, 24, 4, 14, 14), 72, (1, 3, 3), (1, 1, 1), (0, 1, 1)
+    x = torch.randn(shape)
+    w = torch.randn((K, shape[1]) + k) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, s, p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    plan = ops.ConvPlan(*shape, K, k, s, p, DEV)
+    plan.tuned = [False, False, False]                      # force the measurement (the suite default is heuristic)
+    y = ops.conv_fwd(plan, x.to(DEV), ops.conv_pack(plan, 0, w.to(DEV)))
+    dx = ops.conv_dgrad(plan, dy.to(DEV), ops.conv_pack(plan, 1, w.to(DEV)))
+    dw = torch.zeros_like(w).to(DEV)
+    ops.conv_wgrad(plan, x.to(DEV), dy.to(DEV), dw, accumulate=True)
+    assert plan.tuned == [True, True, True]
+    g = plan.g
+    assert g.tune_fwd_bm and g.tune_dgrad_bm and g.tune_wgrad_tile and min(g.tune_fwd_splits, g.tune_dgrad_splits, g.tune_wgrad_splits) >= 1
+    assert rel_err(y, yr) < 1e-5 and rel_err(dx, xr.grad) < 1e-5 and rel_err(dw, wr.grad) < 1e-5
