@@ -504,3 +504,36 @@ def test_autotuner_pins_a_valid_configuration(ops):
     g = plan.g
     assert g.tune_fwd_bm and g.tune_dgrad_bm and g.tune_wgrad_tile and min(g.tune_fwd_splits, g.tune_dgrad_splits, g.tune_wgrad_splits) >= 1
     assert rel_err(y, yr) < 1e-5 and rel_err(dx, xr.grad) < 1e-5 and rel_err(dw, wr.grad) < 1e-5
+
+
+@pytest.mark.parametrize('shape,K,k,s,p', [
+    ((32, 3, 16, 112, 112), 110, (1, 7, 7), (1, 2, 2), (0, 3, 3)),     # R(2+1)D-18 stem, BASELINE configs[1] size
+    ((32, 110, 16, 56, 56), 64, (7, 1, 1), (1, 1, 1), (3, 0, 0)),      # stem temporal conv (158 GFLOP)
+    ((32, 64, 8, 28, 28), 144, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # layer1 spatial conv
+    ((32, 230, 8, 14, 14), 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),      # layer2 strided temporal conv
+    ((32, 512, 1, 4, 4), 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # layer4 (split-K territory)
+])
+def test_conv_full_size_vs_device_reference_and_linearity(ops, shape, K, k, s, p):
+    """BASELINE-size layers (too big for the CPU oracle in test time): all three passes against ATen's own fp32
+    convolution on the same GPU (MIOpen; a different algorithm and summation order, hence 2e-4), plus a
+    size-independent property of the product kernels alone: linearity in the input."""
+    torch.manual_seed(11)
+    x = torch.randn(shape, device=DEV)
+    w = torch.randn((K, shape[1]) + tuple(k), device=DEV) * (1.0 / (shape[1] * k[0] * k[1] * k[2]) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, s, p)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    plan = ops.conv_plan(shape, K, k, s, p, DEV)
+    wp0, wp1 = ops.conv_pack(plan, 0, w), ops.conv_pack(plan, 1, w)
+    y, (ss, sq) = ops.conv_fwd(plan, x, wp0, None, stats=True)
+    assert rel_err(y, yr.detach()) < 2e-4
+    assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-3 and rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-3
+    if shape[1] > 3:
+        assert rel_err(ops.conv_dgrad(plan, dy, wp1), xr.grad) < 2e-4
+    dw = torch.zeros_like(w)
+    ops.conv_wgrad(plan, x, dy, dw, accumulate=True)
+    assert rel_err(dw, wr.grad) < 2e-4
+    x2 = torch.randn(shape, device=DEV)
+    lin = ops.conv_fwd(plan, 0.5 * x - 2.0 * x2, wp0)
+    assert rel_err(lin, 0.5 * y - 2.0 * ops.conv_fwd(plan, x2, wp0)) < 1e-5
