@@ -204,9 +204,11 @@ def infonce_timing(pkg, b=32):
         g = torch.cuda.CUDAGraph()
         f()
         torch.cuda.synchronize()
+        REP = 20                                   # back to back inside one graph: device time of the op, not of a graph launch
         with torch.cuda.graph(g):
-            f()
-        ms = ev_time_ms(g.replay, 200, 10)
+            for _ in range(REP):
+                f()
+        ms = ev_time_ms(g.replay, 50, 5) / REP
         bytes_alg = K * 128 * 4 + 2 * b * 128 * 4 + b * (K + 1) * 4
         out['K%d' % K] = dict(ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2),
                               GBps=round(bytes_alg / 1e9 / (ms / 1e3), 1),

@@ -325,12 +325,13 @@ def test_moco_allk_wrap_and_device_pointer(ops, golden):
     assert torch.equal(mem.cpu(), g.t('allk:mem1')) and int(ptr_dev) == 2
 
 
-@pytest.mark.parametrize('b,K', [(32, 4096), (5, 1000), (40, 65536)])
-def test_infonce_sizes_vs_oracle(ops, b, K):
-    """BASELINE configs' InfoNCE shapes (b=32 K=4096 / 65536) + ragged sizes, vs the oracle."""
+@pytest.mark.parametrize('b,K,D', [(32, 4096, 128), (5, 1000, 128), (40, 65536, 128), (70, 16384, 128), (33, 9000, 64),
+                                   (8, 300, 96), (16, 2048, 136)])
+def test_infonce_sizes_vs_oracle(ops, b, K, D):
+    """BASELINE configs' InfoNCE shapes (b=32 K=4096 / 65536) + ragged sizes, vs the oracle: every workgroup width
+    of the fused kernel (1 / 2 / 4 / 8 waves), several batch tiles, narrower features, and D = 136 (two-pass path)."""
     from oracle.moco import RGBMoCo, NCESoftmaxLoss
     torch.manual_seed(6)
-    D = 128
     mo = RGBMoCo(D, K=K, T=0.07)
     q = F.normalize(torch.randn(b, D)).requires_grad_(True)
     k = F.normalize(torch.randn(b, D))

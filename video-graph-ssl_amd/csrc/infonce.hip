@@ -8,6 +8,7 @@
 //
 // HBM-bound (AI ~ 12.7 F/B at b=32): algorithmic bytes = K*D*4 (queue) + b*(K+1)*4 (logits).
 // Reference: lib/memory/mem_moco.py:14-49,60-88; lib/memory/criterion.py:34-45.
+#include <cstdint>
 #include "gca_common.h"
 #include <math.h>
 
@@ -78,6 +79,168 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_kernel(
       s = gca_wave_sum(s);
       if (lane == 0) logits[(long long)i * ld] = s * inv_T;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused forward for D <= 128 (the MoCo feature width): logits + per-(row, 32-column block) log-sum-exp partials +
+// rank counts in ONE pass over the queue.  One wave = 32 queue rows; a workgroup's waves share the staged q tile.
+// Every global load of a wave is issued up front (float4, lanes along the feature axis), the operands sit in LDS
+// as [row][k] with a (D+4)-float pitch and are read as conflict-free 128-bit fragments (4 k-steps per read, same
+// k-permutation on both operands as in conv3d.hip).  lse_finish_kernel then folds the partials (and the positive
+// column) per batch row, so the (b, K+1) logits are written once and never read back.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int FD = 128;              // max feature width of the fused kernel
+constexpr int FP = FD + 4;           // LDS pitch
+
+__device__ __forceinline__ float half_wave_max_hi(float v) {      // max over the 32 lanes of each wave half -> lanes 16..31 / 48..63
+#define GCA_DPPM(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (x)), __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
+  v = fmaxf(v, GCA_DPPM(v, 0xB1, 0xf));
+  v = fmaxf(v, GCA_DPPM(v, 0x4E, 0xf));
+  v = fmaxf(v, GCA_DPPM(v, 0x141, 0xf));
+  v = fmaxf(v, GCA_DPPM(v, 0x140, 0xf));
+  v = fmaxf(v, GCA_DPPM(v, 0x142, 0xa));
+#undef GCA_DPPM
+  return v;
+}
+__device__ __forceinline__ float half_wave_sum_hi_f(float v) {
+#define GCA_DPPS(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (x)), (ctrl), (rmask), 0xf, false))
+  v += GCA_DPPS(v, 0xB1, 0xf);
+  v += GCA_DPPS(v, 0x4E, 0xf);
+  v += GCA_DPPS(v, 0x141, 0xf);
+  v += GCA_DPPS(v, 0x140, 0xf);
+  v += GCA_DPPS(v, 0x142, 0xa);
+#undef GCA_DPPS
+  return v;
+}
+
+// One wave = 32 queue rows; the waves of a workgroup share the staged q tile.  All global loads are float4 with lanes
+// along the feature axis (whole 512-byte rows), issued before their first use; operands sit in LDS as [row][k] with a
+// (D+4)-float pitch and are read as conflict-free 128-bit k-permuted fragments (4 k-steps per read, as in conv3d.hip).
+// (Tried and dropped: fetching q / k / queue fragments lane-per-row straight into registers -- no LDS, no barriers --
+// which needs ~280 registers and 32 cache lines per load instruction: 2x slower at K = 65536.)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void moco_logits_fused_kernel(
+    const float* __restrict__ q, const float* __restrict__ kpos, const float* __restrict__ queue,
+    int b, long long K, int D, float inv_T, float* __restrict__ logits, int ncb,
+    float* __restrict__ pm, float* __restrict__ ps, float* __restrict__ pc, gca_magic md4) {
+  constexpr int NT = FD / 8;
+  __shared__ __attribute__((aligned(16))) float Qs[32 * FP];           // [32][FP]   q tile, k contiguous
+  __shared__ float L0[32];                                             // positive logits of the tile's batch rows
+  __shared__ __attribute__((aligned(16))) float Ns[WAVES][32 * FP];    // per-wave queue tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lh = lane >> 5, ll = lane & 31;
+  const int blk = blockIdx.x;
+  const long long cb = (long long)blk * WAVES + wave;                  // 32-column block of this wave
+  const long long row0 = cb * 32;
+  const long long ld = K + 1;
+  const int mtiles = (b + 31) / 32;
+  const int d4 = D >> 2, nt = D >> 3;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* Nw = Ns[wave];
+  {  // this wave's 32 queue rows, once: all loads in flight, then LDS (rows past K read as zeros)
+    float4 v[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int i = lane + 64 * it, r = (int)gca_fdiv((unsigned)i, md4), c4 = i - r * d4;
+      v[it] = zero4;
+      if (i < 32 * d4 && row0 + r < K) v[it] = *reinterpret_cast<const float4*>(queue + (row0 + r) * D + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int i = lane + 64 * it, r = (int)gca_fdiv((unsigned)i, md4), c4 = i - r * d4;
+      if (i < 32 * d4) *reinterpret_cast<float4*>(&Nw[r * FP + c4 * 4]) = v[it];
+    }
+  }
+  for (int mt = 0; mt < mtiles; ++mt) {
+    __syncthreads();                              // previous tile's Qs / L0 readers are done
+    for (int i = tid; i < 32 * d4; i += WAVES * 64) {
+      const int m = (int)gca_fdiv((unsigned)i, md4), c4 = i - m * d4, row = mt * 32 + m;
+      *reinterpret_cast<float4*>(&Qs[m * FP + c4 * 4]) = row < b ? *reinterpret_cast<const float4*>(q + (long long)row * D + c4 * 4) : zero4;
+    }
+    // positive logits of these 32 batch rows (every workgroup needs them for the rank counts): wave 0, one batch row
+    // per lane pair -- lane (m, half) walks half of the features of row m
+    __syncthreads();
+    {   // positive logits: 32 rows over WAVES waves, 64/(32/WAVES) lanes per row, float4 pieces strided over the lanes
+      constexpr int RPW = 32 / WAVES;                 // rows per wave
+      constexpr int LPR = 64 / RPW;                   // lanes per row
+      const int m = wave * RPW + lane / LPR, part = lane % LPR;
+      const int row = mt * 32 + m;
+      float sdot = 0.f;
+      for (int c4 = part; c4 < d4; c4 += LPR) {
+        const float4 a = *reinterpret_cast<const float4*>(&Qs[m * FP + c4 * 4]);
+        const float4 kq = row < b ? *reinterpret_cast<const float4*>(kpos + (long long)row * D + c4 * 4) : zero4;
+        sdot += a.x * kq.x + a.y * kq.y + a.z * kq.z + a.w * kq.w;
+      }
+#pragma unroll
+      for (int o = LPR / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+      if (part == 0) L0[m] = sdot * inv_T;
+    }
+    __syncthreads();
+    if (cb == 0 && lane < 32 && mt * 32 + lane < b) logits[(long long)(mt * 32 + lane) * ld] = L0[lane];
+    if (row0 >= K) continue;                                           // (workgroup tail: keeps the barriers uniform)
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < nt; ++t) {
+      const float4 a = *reinterpret_cast<const float4*>(&Qs[ll * FP + 8 * t + 4 * lh]);
+      const float4 bq = *reinterpret_cast<const float4*>(&Nw[ll * FP + 8 * t + 4 * lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, acc, 0, 0, 0);
+    }
+    const long long j = row0 + ll;
+    const bool jv = j < K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int i = mt * 32 + m;
+      const float v = acc[r] * inv_T;
+      if (jv && i < b) logits[(long long)i * ld + 1 + j] = v;
+      if (pm) {
+        const float vm = jv ? v : -INFINITY;
+        const float mx = half_wave_max_hi(vm);                         // valid in lanes 16..31 / 48..63
+        // every lane of the half needs the block maximum: two scalar lane reads instead of an LDS-crossbar shuffle
+        const float mxa = lh ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 63))
+                             : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx), 31));
+        const float e = jv && mxa > -INFINITY ? expf(v - mxa) : 0.f;
+        const float se = half_wave_sum_hi_f(e);
+        const float ge = half_wave_sum_hi_f(jv && v >= L0[m] ? 1.f : 0.f);
+        if (ll == 31 && i < b) { pm[cb * b + i] = mxa; ps[cb * b + i] = se; pc[cb * b + i] = ge; }
+      }
+    }
+  }
+}
+
+// one workgroup per batch row: fold the column-block partials and the positive column
+__global__ __launch_bounds__(256) void lse_finish_kernel(const float* __restrict__ logits, long long ld, int ncb,
+                                                         const float* __restrict__ pm, const float* __restrict__ ps,
+                                                         const float* __restrict__ pc, float* __restrict__ lse,
+                                                         int* __restrict__ rank) {
+  __shared__ float sh[4];
+  __shared__ float shm[4];
+  const long long i = blockIdx.x;
+  const float l0 = logits[i * ld];
+  float m = l0;
+  const long long nb = gridDim.x;                     // partials are [column block][batch row]
+  for (int c = threadIdx.x; c < ncb; c += 256) m = fmaxf(m, pm[(long long)c * nb + i]);
+  m = gca_wave_max(m);
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(shm[0], shm[1]), fmaxf(shm[2], shm[3]));
+  float s = 0.f, c_ = 0.f;
+  for (int c = threadIdx.x; c < ncb; c += 256) {
+    const float pmv = pm[(long long)c * nb + i];
+    if (pmv > -INFINITY) s += ps[(long long)c * nb + i] * expf(pmv - m);
+    c_ += pc[(long long)c * nb + i];
+  }
+  s = gca_block_sum256(s, sh);
+  c_ = gca_block_sum256(c_, sh);
+  if (threadIdx.x == 0) {
+    if (lse) lse[i] = m + logf(s + expf(l0 - m));
+    if (rank) rank[i] = (int)(c_ + 0.5f);
   }
 }
 
@@ -234,9 +397,33 @@ int64_t gca_infonce_ws_bytes(int64_t b, int64_t K) {
 int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
                         int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge,
                         void* ws, void* stream) {
-  (void)ws;
   if (!q || !k || !queue || !logits || b <= 0 || K <= 0 || D <= 0 || (D & 3)) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  const bool want = row_lse || rank_ge;
+  if (D <= FD && (D & 7) == 0 && (!want || ws) && (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)k) % 16) == 0) {
+    // fused path: logits + LSE / rank partials in one pass over the queue, then a per-row fold
+    const int ncb = (int)gca_ceil_div(K, 32);
+    // waves per workgroup: the kernel is one dependent chain per wave (load -> stage -> MFMA -> reduce), so what counts
+    // is running ALL column blocks in one round: as many waves per workgroup as it takes to fit 256 workgroups
+    const int waves = ncb > 1024 ? 8 : (ncb > 512 ? 4 : (ncb > 256 ? 2 : 1));
+    float* pm = want ? reinterpret_cast<float*>(ws) : nullptr;
+    float* ps = want ? pm + (long long)b * ncb : nullptr;
+    float* pc = want ? ps + (long long)b * ncb : nullptr;
+    const gca_magic md4 = gca_make_magic((unsigned)(D >> 2));
+    const dim3 grid((unsigned)gca_ceil_div(ncb, waves));
+#define GCA_FUSED(W) hipLaunchKernelGGL((moco_logits_fused_kernel<W>), grid, dim3(64 * W), 0, st, q, k, queue, (int)b, \
+                                        (long long)K, (int)D, inv_T, logits, ncb, pm, ps, pc, md4)
+    if (waves == 8) GCA_FUSED(8);
+    else if (waves == 4) GCA_FUSED(4);
+    else if (waves == 2) GCA_FUSED(2);
+    else GCA_FUSED(1);
+#undef GCA_FUSED
+    int rc = gca_launch_status();
+    if (rc || !want) return rc;
+    hipLaunchKernelGGL(lse_finish_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, (long long)(K + 1), ncb, pm, ps, pc,
+                       row_lse, rank_ge);
+    return gca_launch_status();
+  }
   if (K >= 32768)
     hipLaunchKernelGGL((moco_logits_kernel<4>), dim3((unsigned)gca_ceil_div(K, 128)), dim3(256), 0, st, q, k, queue,
                        (int)b, (long long)K, (int)D, inv_T, logits);

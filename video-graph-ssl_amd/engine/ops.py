@@ -452,8 +452,9 @@ def moco_logits_fwd(q, k, queue, inv_T, want_lse=False, want_rank=False):
     logits = torch.empty((b, K + 1), dtype=F32, device=q.device)
     lse = torch.empty(b, dtype=F32, device=q.device) if want_lse else None
     rank = torch.empty(b, dtype=torch.int32, device=q.device) if want_rank else None
+    ws = WS.get(H.lib.gca_infonce_ws_bytes(b, K), q.device) if (want_lse or want_rank) else None
     H.call('gca_moco_logits_fwd', ptr(q), ptr(k), ptr(queue), b, K, D, float(inv_T), ptr(logits), ptr(lse), ptr(rank),
-           None, stream())
+           ptr(ws), stream())
     return logits, lse, rank
 
 
