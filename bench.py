@@ -199,8 +199,7 @@ def infonce_timing(pkg, b=32):
         mem = torch.nn.functional.normalize(torch.randn(K, 128, device='cuda'))
 
         def f():
-            logits, lse, rank = ops.moco_logits_fwd(q, k, mem, 1 / 0.07, want_lse=True, want_rank=True)
-            ops.nce_loss_fwd(logits, lse)
+            ops.moco_logits_fwd(q, k, mem, 1 / 0.07, want_lse=True, want_rank=True, want_loss=True)   # logits, lse, rank, loss
         g = torch.cuda.CUDAGraph()
         f()
         torch.cuda.synchronize()

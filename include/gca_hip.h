@@ -194,12 +194,13 @@ int gca_negcos_fwd_bwd(const float* p, const float* z, int64_t rows, int64_t dim
  * streaming the queue once.  NCESoftmaxLoss (lib/memory/criterion.py:34-45) = mean_i
  * (logsumexp(logits_i) - logits_i0).  _update_memory/_update_pointer (mem_moco.py:14-27).
  * ------------------------------------------------------------------------------------- */
-/* logits (b, K+1).  Optional fused row statistics (any may be NULL): row_lse (b), and
- * rank_ge (b) = number of negatives with logit >= the positive's (top-1 hit <=> 0, top-5 <=> < 5;
- * lib/evaluation/metric.py:44-67 with label 0).  ws: gca_infonce_ws_bytes(b, K). */
+/* logits (b, K+1).  Optional fused row statistics (any may be NULL): row_lse (b), rank_ge (b) = number of negatives
+ * with logit >= the positive's (top-1 hit <=> 0, top-5 <=> < 5; lib/evaluation/metric.py:44-67 with label 0), and
+ * loss (1) = NCESoftmaxLoss of these logits (needs row_lse) -- the whole forward of mem_moco.py:60-88 +
+ * criterion.py:34-45 behind one call.  ws: gca_infonce_ws_bytes(b, K). */
 int64_t gca_infonce_ws_bytes(int64_t b, int64_t K);
 int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
-                        int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge,
+                        int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge, float* loss,
                         void* ws, void* stream);
 /* loss = mean_i (lse_i - logits[i,0]); lse computed here if row_lse_in == NULL. */
 int gca_nce_softmax_loss_fwd(const float* logits, int64_t b, int64_t ncol, const float* row_lse_in,

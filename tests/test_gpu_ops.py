@@ -344,6 +344,9 @@ def test_infonce_sizes_vs_oracle(ops, b, K, D):
     assert rel_err(logits, logits_r) < 1e-5
     loss, _ = ops.nce_loss_fwd(logits, lse)
     assert rel_err(loss, loss_r.detach().reshape(1)) < 1e-5
+    l2, lse2, rank2, loss2 = ops.moco_logits_fwd(q.detach().to(DEV), k.to(DEV), mem, 1 / 0.07, True, True, want_loss=True)
+    assert torch.equal(l2, logits) and torch.equal(lse2, lse) and torch.equal(rank2, rank)      # loss fused into the same launches
+    assert rel_err(loss2, loss_r.detach().reshape(1)) < 1e-5
     dq = ops.moco_logits_bwd(k.to(DEV), mem, 1 / 0.07, logits=logits, lse=lse)
     assert rel_err(dq, q.grad) < 1e-4
     want_rank = (logits_r.detach()[:, 1:] >= logits_r.detach()[:, :1]).sum(1)

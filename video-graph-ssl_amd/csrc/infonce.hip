@@ -395,11 +395,12 @@ int64_t gca_infonce_ws_bytes(int64_t b, int64_t K) {
 }
 
 int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
-                        int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge,
+                        int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge, float* loss,
                         void* ws, void* stream) {
   if (!q || !k || !queue || !logits || b <= 0 || K <= 0 || D <= 0 || (D & 3)) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const bool want = row_lse || rank_ge;
+  const bool want = row_lse || rank_ge || loss;
+  if (loss && !row_lse) return GCA_EINVAL;          // the loss needs the row log-sum-exps (kept for the backward anyway)
   if (D <= FD && (D & 7) == 0 && (!want || ws) && (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)k) % 16) == 0) {
     // fused path: logits + LSE / rank partials in one pass over the queue, then a per-row fold
     const int ncb = (int)gca_ceil_div(K, 32);
@@ -420,8 +421,12 @@ int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int6
 #undef GCA_FUSED
     int rc = gca_launch_status();
     if (rc || !want) return rc;
+    // (a single-workgroup fold that also reduces the loss was tried for b*K small: 8 us slower than these two launches)
     hipLaunchKernelGGL(lse_finish_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, (long long)(K + 1), ncb, pm, ps, pc,
                        row_lse, rank_ge);
+    rc = gca_launch_status();
+    if (rc || !loss) return rc;
+    hipLaunchKernelGGL(nce_loss_finish_kernel, dim3(1), dim3(256), 0, st, logits, row_lse, (int)b, (long long)(K + 1), loss);
     return gca_launch_status();
   }
   if (K >= 32768)
@@ -434,6 +439,10 @@ int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int6
   if (rc) return rc;
   if (row_lse || rank_ge) {
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)b), dim3(256), 0, st, logits, (long long)(K + 1), row_lse, rank_ge);
+    rc = gca_launch_status();
+  }
+  if (!rc && loss) {
+    hipLaunchKernelGGL(nce_loss_finish_kernel, dim3(1), dim3(256), 0, st, logits, row_lse, (int)b, (long long)(K + 1), loss);
     rc = gca_launch_status();
   }
   return rc;

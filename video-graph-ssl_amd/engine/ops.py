@@ -446,16 +446,20 @@ def negcos(p, z, scale, loss_buf, accumulate):
 
 
 # ----------------------------------------------------------------------------- MoCo / InfoNCE
-def moco_logits_fwd(q, k, queue, inv_T, want_lse=False, want_rank=False):
+def moco_logits_fwd(q, k, queue, inv_T, want_lse=False, want_rank=False, want_loss=False):
+    """-> (logits, lse, rank) [+ (loss,) when want_loss: the InfoNCE loss of these logits, fused into the same two
+    launches -- the separate nce_loss_fwd call is then unnecessary]."""
     b, D = q.shape
     K = queue.shape[0]
+    want_lse = want_lse or want_loss
     logits = torch.empty((b, K + 1), dtype=F32, device=q.device)
     lse = torch.empty(b, dtype=F32, device=q.device) if want_lse else None
     rank = torch.empty(b, dtype=torch.int32, device=q.device) if want_rank else None
+    loss = torch.empty(1, dtype=F32, device=q.device) if want_loss else None
     ws = WS.get(H.lib.gca_infonce_ws_bytes(b, K), q.device) if (want_lse or want_rank) else None
     H.call('gca_moco_logits_fwd', ptr(q), ptr(k), ptr(queue), b, K, D, float(inv_T), ptr(logits), ptr(lse), ptr(rank),
-           ptr(ws), stream())
-    return logits, lse, rank
+           ptr(loss), ptr(ws), stream())
+    return (logits, lse, rank, loss) if want_loss else (logits, lse, rank)
 
 
 def nce_loss_fwd(logits, lse=None):

@@ -134,8 +134,8 @@ class MoCoTrainer(object):
         tape = Tape(True)
         qv = self.model.fwd(tape, Var(torch.chunk(s['images'], 2, dim=1)[0]))
         mem = self.contrast.memory
-        logits, lse, rank = ops.moco_logits_fwd(qv.t, s['k'], mem, self.inv_T, want_lse=True, want_rank=True)
-        loss, _ = ops.nce_loss_fwd(logits, lse)
+        logits, lse, rank, loss = ops.moco_logits_fwd(qv.t, s['k'], mem, self.inv_T, want_lse=True, want_rank=True,
+                                                      want_loss=True)
         saved = ops.queue_enqueue(mem, s['all_k'], 0, save=True, ptr_dev=self.ptr_dev)
         # DDP averages gradients: fold 1/world into the loss-gradient scale
         qv.grad = ops.moco_logits_bwd(s['k'], mem, self.inv_T, logits=logits, lse=lse,
