@@ -245,6 +245,80 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+// Whole BatchNorm backward of one channel in ONE workgroup (small N*SP: the deep, narrow layers and every layer of
+// a small batch): pass 1 reduces (sum dz, sum dz*xhat) in fp64, the block derives the coefficients and accumulates
+// dgamma / dbeta, pass 2 re-reads the (L2-resident) operands and writes dx (+ the residual gradient).  Replaces
+// three launches (reduce, finalize, apply) that cost more in launch latency than in work at these sizes.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_small_kernel(
+    const float* __restrict__ dzin, const float* __restrict__ z, const float* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+    int N, int C, int SP, long long zs, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dres, int dres_acc, const float* __restrict__ scale, const float* __restrict__ shift) {
+  __shared__ double sh[4];
+  const int c = blockIdx.x;
+  const float mu = mean[c], is = invstd[c];
+  const float rsc = relu == 2 ? scale[c] : 0.f, rsf = relu == 2 ? shift[c] : 0.f;
+  const int per = SP / VEC, total = N * per;                 // VEC-wide slots of this channel
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int n = i / per, sp = (i - n * per) * VEC;
+    const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
+    float dv[VEC], xv[VEC], zv[VEC];
+    if (VEC == 4) {
+      const float4 d4 = *reinterpret_cast<const float4*>(dzin + zi), x4 = *reinterpret_cast<const float4*>(x + xi);
+      dv[0] = d4.x; dv[VEC > 1 ? 1 : 0] = d4.y; dv[VEC > 2 ? 2 : 0] = d4.z; dv[VEC > 3 ? 3 : 0] = d4.w;
+      xv[0] = x4.x; xv[VEC > 1 ? 1 : 0] = x4.y; xv[VEC > 2 ? 2 : 0] = x4.z; xv[VEC > 3 ? 3 : 0] = x4.w;
+      if (relu == 1) { const float4 z4 = *reinterpret_cast<const float4*>(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
+    } else { dv[0] = dzin[zi]; xv[0] = x[xi]; if (relu == 1) zv[0] = z[zi]; }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float d = dv[e];
+      if (relu == 1 && !(zv[e] > 0.f)) d = 0.f;
+      if (relu == 2 && !(xv[e] * rsc + rsf > 0.f)) d = 0.f;
+      s0 += (double)d; s1 += (double)d * (double)((xv[e] - mu) * is);
+    }
+  }
+  s0 = gca_block_sum256_d(s0, sh);
+  s1 = gca_block_sum256_d(s1, sh);
+  const double count = (double)N * (double)SP;
+  if (threadIdx.x == 0) {
+    if (dbeta) dbeta[c] += (float)s0;
+    if (dgamma) dgamma[c] += (float)s1;
+  }
+  const float A = (gamma ? gamma[c] : 1.f) * is, B = (float)(s0 / count), Cc = (float)(s1 / count);
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int n = i / per, sp = (i - n * per) * VEC;
+    const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
+    float dv[VEC], xv[VEC], zv[VEC], ov[VEC];
+    if (VEC == 4) {
+      const float4 d4 = *reinterpret_cast<const float4*>(dzin + zi), x4 = *reinterpret_cast<const float4*>(x + xi);
+      dv[0] = d4.x; dv[VEC > 1 ? 1 : 0] = d4.y; dv[VEC > 2 ? 2 : 0] = d4.z; dv[VEC > 3 ? 3 : 0] = d4.w;
+      xv[0] = x4.x; xv[VEC > 1 ? 1 : 0] = x4.y; xv[VEC > 2 ? 2 : 0] = x4.z; xv[VEC > 3 ? 3 : 0] = x4.w;
+      if (relu == 1) { const float4 z4 = *reinterpret_cast<const float4*>(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
+    } else { dv[0] = dzin[zi]; xv[0] = x[xi]; if (relu == 1) zv[0] = z[zi]; }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      if (relu == 1 && !(zv[e] > 0.f)) dv[e] = 0.f;
+      if (relu == 2 && !(xv[e] * rsc + rsf > 0.f)) dv[e] = 0.f;
+      ov[e] = A * (dv[e] - B - (xv[e] - mu) * is * Cc);
+    }
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(dx + xi) = make_float4(ov[0], ov[VEC > 1 ? 1 : 0], ov[VEC > 2 ? 2 : 0], ov[VEC > 3 ? 3 : 0]);
+      if (dres) {
+        float4 r = make_float4(dv[0], dv[VEC > 1 ? 1 : 0], dv[VEC > 2 ? 2 : 0], dv[VEC > 3 ? 3 : 0]);
+        if (dres_acc) { const float4 o = *reinterpret_cast<const float4*>(dres + xi); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+        *reinterpret_cast<float4*>(dres + xi) = r;
+      }
+    } else {
+      dx[xi] = ov[0];
+      if (dres) dres[xi] = dres_acc ? dres[xi] + dv[0] : dv[0];
+    }
+  }
+}
+
+constexpr long long BN_SMALL_ELEMS = 32768;          // N*SP at or below this: one workgroup per channel
+
 inline unsigned ew_grid(long long total, int vec) {
   long long b = gca_ceil_div(total, 256LL * vec);
   if (b > 8192) b = 8192;          // grid-stride the rest
@@ -325,6 +399,17 @@ int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* 
   if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
   const long long zs = z_batch_stride ? z_batch_stride : C * SP;
   hipStream_t st = (hipStream_t)stream;
+  if (N * SP <= BN_SMALL_ELEMS && N * C * SP < (1LL << 31)) {
+    const bool s4 = (SP % 4 == 0) && (zs % 4 == 0) &&
+                    (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
+    if (s4)
+      hipLaunchKernelGGL((bn_bwd_small_kernel<4>), dim3((unsigned)C), dim3(256), 0, st, dz_in, z, x, gamma, save_mean, save_invstd,
+                         relu, (int)N, (int)C, (int)SP, zs, dx, dgamma, dbeta, dres, dres_accumulate, scale, shift);
+    else
+      hipLaunchKernelGGL((bn_bwd_small_kernel<1>), dim3((unsigned)C), dim3(256), 0, st, dz_in, z, x, gamma, save_mean, save_invstd,
+                         relu, (int)N, (int)C, (int)SP, zs, dx, dgamma, dbeta, dres, dres_accumulate, scale, shift);
+    return gca_launch_status();
+  }
   const int P = (int)stats_parts(N, C, SP);
   float* p0 = reinterpret_cast<float*>(ws);
   float* p1 = p0 + (long long)C * P;
