@@ -130,6 +130,14 @@ int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int6
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+/* gca_bn_finalize followed by gca_bn_apply behind one call (one LAUNCH when N*SP is small: the deep layers, and
+ * every layer of a small batch, are launch-latency bound).  count must equal N*SP. */
+int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* save_mean, float* save_invstd, float* scale, float* shift,
+                     const float* x, const float* residual, int relu, int64_t N, int64_t SP, float* z,
+                     int64_t z_batch_stride, void* stream);
 /* Eval-mode fold (running stats): scale/shift only. */
 int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int64_t C, float* scale, float* shift, void* stream);

@@ -541,3 +541,42 @@ def test_conv_full_size_vs_device_reference_and_linearity(ops, shape, K, k, s, p
     x2 = torch.randn(shape, device=DEV)
     lin = ops.conv_fwd(plan, 0.5 * x - 2.0 * x2, wp0)
     assert rel_err(lin, 0.5 * y - 2.0 * ops.conv_fwd(plan, x2, wp0)) < 1e-5
+
+
+@pytest.mark.parametrize('N,C,SP,res', [(4, 10, 48, True), (3, 7, 30, False), (2, 5, 20000, True), (8, 6, 1, False)])
+def test_bn_train_fwd_and_small_bwd_equal_the_separate_passes(ops, N, C, SP, res):
+    """gca_bn_train_fwd (finalize + apply, ONE launch when N*SP is small) and the one-launch small BatchNorm backward
+    against the separate reduce / finalize / apply kernels (N*SP = 40000 takes those), same inputs."""
+    torch.manual_seed(12)
+    x = torch.randn(N, C, SP, device=DEV) * 2 + 0.3
+    r = torch.randn(N, C, SP, device=DEV) if res else None
+    gam, bet = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    ss, sq = ops.bn_stats(x, N, C, SP)
+
+    def fresh():
+        return torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    rm0, rv0, nb0 = fresh()
+    mean, invstd, scale, shift = ops.bn_finalize(ss, sq, N * SP, gam, bet, 1e-5, 0.1, rm0, rv0, nb0)
+    z0 = ops.bn_apply(x, scale, shift, r, True, N, C, SP)
+    rm1, rv1, nb1 = fresh()
+    z1, mean1, invstd1, scale1, shift1 = ops.bn_train_fwd(ss, sq, N * SP, gam, bet, 1e-5, 0.1, rm1, rv1, nb1, x, r, True, N, C, SP)
+    assert torch.equal(z0, z1) and torch.equal(mean, mean1) and torch.equal(invstd, invstd1) and torch.equal(scale, scale1)
+    assert torch.equal(rm0, rm1) and torch.equal(rv0, rv1) and int(nb1) == 1
+    # backward against an autograd reference of the same op
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    gr, br = gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    y = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    zr = F.relu(y + rr if res else y)
+    dz = torch.randn_like(zr)
+    zr.backward(dz)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dres = torch.empty_like(x) if res else None
+    dx = ops.bn_bwd(dz, z1, x, gam, mean, invstd, 1, N, C, SP, dg, db, dres, False)
+    assert rel_err(dx, xr.grad) < 1e-4 and rel_err(dg, gr.grad) < 1e-4 and rel_err(db, br.grad) < 1e-4
+    if res:
+        assert rel_err(dres, rr.grad) < 1e-6
+    else:      # no residual: the mask can come from x instead of z
+        dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dx2 = ops.bn_bwd(dz, None, x, gam, mean, invstd, 2, N, C, SP, dg2, db2, None, False, scale, shift)
+        assert torch.equal(dx2, dx) and torch.equal(dg2, dg)

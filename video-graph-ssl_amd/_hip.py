@@ -60,6 +60,8 @@ SIGNATURES = {
     'gca_bn_stats_parts': (c_i64, [c_i64, c_i64, c_i64]),
     'gca_bn_finalize': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'gca_bn_train_fwd': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
+                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'gca_bn_fold_eval': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp]),
     'gca_bn_apply': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'gca_bn_bwd_ws_bytes': (c_i64, [c_i64, c_i64, c_i64]),

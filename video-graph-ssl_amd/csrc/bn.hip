@@ -8,6 +8,7 @@ namespace {
 
 constexpr int STAT_CHUNK = 8192;     // elements of one channel handled per stats block
 constexpr int MAX_PARTS = 256;
+constexpr long long BN_SMALL_ELEMS = 32768;   // N*SP at or below this: forward / backward of a channel in one workgroup
 
 __host__ __device__ inline long long stats_parts(long long N, long long C, long long SP) {
   long long p = (N * SP + STAT_CHUNK - 1) / STAT_CHUNK;
@@ -245,6 +246,64 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
   }
 }
 
+// Training-mode BatchNorm forward of one channel in ONE workgroup (small N*SP): fold the conv epilogue's partial sums
+// (fp64, as bn_finalize_kernel), update the running statistics, then normalise the channel (+residual, +ReLU, concat
+// slice) -- finalize and apply in one launch.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_fwd_small_kernel(
+    const float* __restrict__ psum, const float* __restrict__ psq, long long P, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean, float* __restrict__ sinvstd,
+    float* __restrict__ scale, float* __restrict__ shift, long long* __restrict__ nbt,
+    const float* __restrict__ x, const float* __restrict__ res, int relu, int N, int C, int SP, long long zs,
+    float* __restrict__ z) {
+  __shared__ double sh[4];
+  __shared__ float ab[2];
+  const int c = blockIdx.x;
+  if (nbt && c == 0 && threadIdx.x == 0) *nbt += 1;
+  double s = 0.0, q = 0.0;
+  for (long long i = threadIdx.x; i < P; i += 256) { s += (double)psum[c * P + i]; q += (double)psq[c * P + i]; }
+  s = gca_block_sum256_d(s, sh);
+  q = gca_block_sum256_d(q, sh);
+  if (threadIdx.x == 0) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    if (smean) smean[c] = (float)m;
+    if (sinvstd) sinvstd[c] = (float)is;
+    if (rmean) rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * m);
+    if (rvar) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * (float)is;
+    const float sf = b - (float)m * sc;
+    scale[c] = sc; shift[c] = sf;
+    ab[0] = sc; ab[1] = sf;
+  }
+  __syncthreads();
+  const float sc = ab[0], sf = ab[1];
+  const int per = SP / VEC, total = N * per;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int n = i / per, sp = (i - n * per) * VEC;
+    const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
+    if (VEC == 4) {
+      float4 v = *reinterpret_cast<const float4*>(x + xi);
+      v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
+      if (res) { const float4 r = *reinterpret_cast<const float4*>(res + xi); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(z + zi) = v;
+    } else {
+      float v = x[xi] * sc + sf;
+      if (res) v += res[xi];
+      if (relu) v = fmaxf(v, 0.f);
+      z[zi] = v;
+    }
+  }
+}
+
 // Whole BatchNorm backward of one channel in ONE workgroup (small N*SP: the deep, narrow layers and every layer of
 // a small batch): pass 1 reduces (sum dz, sum dz*xhat) in fp64, the block derives the coefficients and accumulates
 // dgamma / dbeta, pass 2 re-reads the (L2-resident) operands and writes dx (+ the residual gradient).  Replaces
@@ -317,8 +376,6 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
   }
 }
 
-constexpr long long BN_SMALL_ELEMS = 32768;          // N*SP at or below this: one workgroup per channel
-
 inline unsigned ew_grid(long long total, int vec) {
   long long b = gca_ceil_div(total, 256LL * vec);
   if (b > 8192) b = 8192;          // grid-stride the rest
@@ -357,6 +414,35 @@ int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int6
                      (long long)P, count, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
                      save_invstd, scale, shift, (long long*)num_batches_tracked);
   return gca_launch_status();
+}
+
+int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* save_mean, float* save_invstd, float* scale, float* shift,
+                     const float* x, const float* residual, int relu, int64_t N, int64_t SP, float* z,
+                     int64_t z_batch_stride, void* stream) {
+  if (!x || !z || N <= 0 || SP <= 0 || (double)N * (double)SP != count) return GCA_EINVAL;
+  if (!stat_sum || !stat_sq || P <= 0 || C <= 0 || !scale || !shift) return GCA_EINVAL;
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  if (N * SP <= BN_SMALL_ELEMS && N * C * SP < (1LL << 31)) {
+    const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+    const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)x | (uintptr_t)z | (uintptr_t)residual) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (v4)
+      hipLaunchKernelGGL((bn_fwd_small_kernel<4>), dim3((unsigned)C), dim3(256), 0, st, stat_sum, stat_sq, (long long)P, count,
+                         gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                         (long long*)num_batches_tracked, x, residual, relu, (int)N, (int)C, (int)SP, zs, z);
+    else
+      hipLaunchKernelGGL((bn_fwd_small_kernel<1>), dim3((unsigned)C), dim3(256), 0, st, stat_sum, stat_sq, (long long)P, count,
+                         gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                         (long long*)num_batches_tracked, x, residual, relu, (int)N, (int)C, (int)SP, zs, z);
+    return gca_launch_status();
+  }
+  int rc = gca_bn_finalize(stat_sum, stat_sq, P, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, save_mean, save_invstd, scale, shift, stream);
+  if (rc) return rc;
+  return gca_bn_apply(x, scale, shift, residual, relu, N, C, SP, z, z_batch_stride, stream);
 }
 
 int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,

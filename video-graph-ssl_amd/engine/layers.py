@@ -219,12 +219,14 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
     train = bn.training
     if train:
         y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True)
-        mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
+        z, mean, invstd, scale, shift = ops.bn_train_fwd(ss, sq, N * SP, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,
+                                                         bn.running_mean, bn.running_var, bn.num_batches_tracked, y,
+                                                         None if residual is None else residual.t, relu, N, K, SP, out=out)
     else:
         y = ops.conv_fwd(plan, x, wp, None)
         mean = invstd = None
         scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
-    z = ops.bn_apply(y, scale, shift, None if residual is None else residual.t, relu, N, K, SP, out=out)
+        z = ops.bn_apply(y, scale, shift, None if residual is None else residual.t, relu, N, K, SP, out=out)
     zv = Var(z, tape.recording)
     if tape.recording:
         if not train:
@@ -301,11 +303,13 @@ def f_bn1d_act(tape, bn, xv, relu):
     b, Cc = x.shape
     if bn.training:
         ss, sq = ops.bn_stats(x, b, Cc, 1)
-        mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, b)
+        z, mean, invstd, scale, shift = ops.bn_train_fwd(ss, sq, b, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,
+                                                         bn.running_mean, bn.running_var, bn.num_batches_tracked, x, None,
+                                                         relu, b, Cc, 1)
     else:
         mean = invstd = None
         scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
-    z = ops.bn_apply(x, scale, shift, None, relu, b, Cc, 1)
+        z = ops.bn_apply(x, scale, shift, None, relu, b, Cc, 1)
     zv = Var(z, tape.recording)
 
     def back():

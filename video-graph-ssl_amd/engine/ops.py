@@ -325,6 +325,18 @@ def bn_finalize(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt):
     return out[0], out[1], out[2], out[3]
 
 
+def bn_train_fwd(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt, x, residual, relu, N, Cc, SP, out=None):
+    """bn_finalize + bn_apply behind one call (one launch for small N*SP).
+    -> (z, save_mean, save_invstd, scale, shift); running stats updated in place."""
+    P = ss.shape[1]
+    st = torch.empty((4, Cc), dtype=F32, device=ss.device)
+    z = torch.empty_like(x) if out is None else out
+    H.call('gca_bn_train_fwd', ptr(ss), ptr(sq), P, Cc, float(count), ptr(gamma), ptr(beta), float(eps), float(momentum),
+           ptr(rmean), ptr(rvar), ptr(nbt), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(x), ptr(residual),
+           int(relu), N, SP, ptr(z), _slice_stride(z, Cc, SP), stream())
+    return z, st[0], st[1], st[2], st[3]
+
+
 def bn_fold_eval(gamma, beta, rmean, rvar, eps):
     Cc = rmean.numel()
     out = torch.empty((2, Cc), dtype=F32, device=rmean.device)
