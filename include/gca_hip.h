@@ -56,6 +56,8 @@ typedef struct {
                                                  gathers (pointwise-in-space convs only); split-K factor */
   int32_t tune_dgrad_bm, tune_dgrad_splits;
   int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile shape index 1..10 (see gca_conv_wgrad_cfg), 0 = heuristic */
+  int32_t tune_fwd_tail, tune_dgrad_tail;      /* two-phase launch: (short tile rows / 32) | (column tiles run with the tall
+                                                  tile << 8); 0 = single launch.  Used only with 128-column tiles, split 1 */
 } gca_conv_geom;
 
 /* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward

@@ -102,6 +102,26 @@ def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
             assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4
             assert rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-4
     assert len(seen) >= 8
+    # two-phase launches: tall tiles over the first column tiles, short tiles over the rest (unit-stride passes only)
+    for which, Ntot in ((0, yr.numel() // K), (1, x.numel() // shape[1])):
+        tilesN = -(-Ntot // 128)
+        if tilesN < 2 or (which == 1 and tuple(s) != (1, 1, 1)):
+            continue
+        for bm, tail in ((64, 1), (160, 2), (96, 1)):
+            for mc in sorted({1, tilesN // 2, tilesN - 1}):
+                if mc < 1:
+                    continue
+                plan.g.tune_fwd_bm = plan.g.tune_dgrad_bm = bm
+                plan.g.tune_fwd_splits = plan.g.tune_dgrad_splits = 1
+                plan.g.tune_fwd_tail = plan.g.tune_dgrad_tail = tail | (mc << 8)
+                plan.refresh()
+                if which == 0:
+                    y, (ss, sq) = ops.conv_fwd(plan, xd, ops.conv_pack(plan, 0, wd), None, stats=True)
+                    assert rel_err(y, yr) < 1e-5, (bm, tail, mc)
+                    assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4 and rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-4
+                else:
+                    assert rel_err(ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd)), xr.grad) < 1e-5, (bm, tail, mc)
+    plan.g.tune_fwd_tail = plan.g.tune_dgrad_tail = 0
     # every wgrad tile shape (1..10; shapes not built for this tap count fall back to the heuristic one)
     seen_w = set()
     for idx in range(1, 11):

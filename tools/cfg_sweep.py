@@ -12,6 +12,7 @@ from conv_micro import LAYERS, ev
 ap = argparse.ArgumentParser()
 ap.add_argument('--layers', default='L01,L03,L14')
 ap.add_argument('--splits', default='1')
+ap.add_argument('--tails', default='', help='two-phase: slots guesses, e.g. 512,768,1024,1280 (tail rows 32 and 64 tried)')
 ap.add_argument('--tiles', default='32,64,96,128,160,1088,1152')
 a = ap.parse_args()
 dev = torch.device('cuda:0')
@@ -37,3 +38,24 @@ for name in a.layers.split(','):
                 print(name, bm, sp, 'ERR', e); continue
             print('%s tile %3d split %2d  cfg f%s d%s | fwd %7.3f ms %6.1f TF | dgrad %7.3f ms %6.1f TF' %
                   (name, bm, sp, plan.cfg(0), plan.cfg(1), tf, fl / 1e9 / tf, td, fl / 1e9 / td), flush=True)
+            if a.tails and sp == 1 and bm < 1024 and bm > 32:
+                for which, M, Nt in ((0, K, N * OD * OH * OW), (1, C, 32 * D * H * W)):
+                    tilesM, tilesN = -(-M // bm), -(-Nt // 128)
+                    for slots in [int(v) for v in a.tails.split(',')]:
+                        mc = (tilesM * tilesN // slots) * slots // tilesM
+                        if mc <= 0 or mc >= tilesN:
+                            continue
+                        for tr in (32, 64):
+                            if tr >= bm:
+                                continue
+                            code = (tr // 32) | (mc << 8)
+                            if which == 0:
+                                plan.g.tune_fwd_tail = code
+                            else:
+                                plan.g.tune_dgrad_tail = code
+                            plan.refresh()
+                            t = ev(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5) if which == 0 else ev(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5)
+                            print('      %s two-phase: slots %4d main cols %5d/%d tail rows %2d  %7.3f ms %6.1f TF' %
+                                  ('fwd  ' if which == 0 else 'dgrad', slots, mc, tilesN, tr, t, fl / 1e9 / t), flush=True)
+                    plan.g.tune_fwd_tail = plan.g.tune_dgrad_tail = 0
+                    plan.refresh()

@@ -49,6 +49,7 @@ struct IgemmParams {
   int ntaps;               // taps of this class (FAST: <= 62)
   int Kpad, Mpad;
   int tilesM, tilesN;
+  int tileN_off;           // first column tile of this launch (two-phase launches: tall tiles, then a short-tile tail)
   int splits, kt_per_split;
   int P;                   // stat partials per channel
   int chk;                 // bit0: test D, bit1: test H, bit2: test W
@@ -72,25 +73,26 @@ struct IgemmParams {
 // ---------------------------------------------------------------------------------------------
 constexpr int LDK = BK + 4;     // LDS row pitch in floats (80 B)
 
+// The tile body is a device function so that ONE launch can mix two tile heights (conv_igemm_2phase_kernel below):
+// `bid` is the workgroup's logical id inside its phase, As_/Bs_/taptab the workgroup's LDS (sized by the caller).
 template <int TM, int BN, int FAST, bool VEC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(
+__device__ __forceinline__ void igemm_tile(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
-    float* __restrict__ psq, float* __restrict__ slab, IgemmParams p) {
-  constexpr int BM = 32 * TM, TN = BN / 128, WN = 4;
+    float* __restrict__ psq, float* __restrict__ slab, const IgemmParams p, int bid,
+    float* __restrict__ As_, float* __restrict__ Bs_, int* __restrict__ taptab) {
+  constexpr int BM = 32 * TM, TN = BN / 128;
   constexpr int A_F4 = (BM * 4 + 255) / 256;               // float4 loads per thread for the A tile (BM x 16)
   constexpr int B_PER = VEC ? 4 : 8;                       // gathers per thread for the B tile
   static_assert(!VEC || (BN == 256 && FAST == 1), "VEC variant: 256 columns, <= 32-tap mask path");
   static_assert(BN == 128 || BN == 256, "BN");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDK];
-  __shared__ int taptab[64];
+  float (*As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(As_);          // [2][BM][LDK]
+  float (*Bs)[BN][LDK] = reinterpret_cast<float (*)[BN][LDK]>(Bs_);          // [2][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-  int bid = gca_xcd_remap(blockIdx.x, gridDim.x);
   const int split = bid % p.splits; bid /= p.splits;
-  const int tileM = bid % p.tilesM, tileN = bid / p.tilesM;
+  const int tileM = bid % p.tilesM, tileN = p.tileN_off + bid / p.tilesM;
 
   if (FAST) {
     if (tid < 64) taptab[tid] = reinterpret_cast<const int*>(table + p.Kpad)[tid];
@@ -418,6 +420,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
   }
 }
 
+template <int TM, int BN, int FAST, bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(
+    const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
+    const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
+    float* __restrict__ psq, float* __restrict__ slab, IgemmParams p) {
+  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs_[2 * BN * LDK];
+  __shared__ int taptab[64];
+  igemm_tile<TM, BN, FAST, VEC>(src, apack, table, bias, dst, psum, psq, slab, p, gca_xcd_remap(blockIdx.x, gridDim.x), As_, Bs_,
+                                taptab);
+}
+
+// Two tile heights in ONE launch: workgroups [0, nA) run TMA-row tiles over the first p.tilesN column tiles, the rest run
+// TMB-row tiles over the remaining ones.  Workgroups are dispatched in id order, so the short tiles flow into the CUs
+// that the last, partly filled wave of tall workgroups leaves idle (a second LAUNCH would wait for that wave to end).
+template <int TMA, int TMB, int FAST>
+__global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
+    const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
+    const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
+    float* __restrict__ psq, IgemmParams p, int nA, int tilesM_B, int tilesN_B) {
+  static_assert(TMB < TMA, "the tail uses the shorter tile");
+  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TMA * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs_[2 * 128 * LDK];
+  __shared__ int taptab[64];
+  if ((int)blockIdx.x < nA) {
+    igemm_tile<TMA, 128, FAST, false>(src, apack, table, bias, dst, psum, psq, nullptr, p, gca_xcd_remap(blockIdx.x, nA), As_, Bs_, taptab);
+  } else {
+    IgemmParams pb = p;
+    pb.tileN_off = p.tileN_off + p.tilesN;
+    pb.tilesM = tilesM_B; pb.tilesN = tilesN_B;
+    igemm_tile<TMB, 128, FAST, false>(src, apack, table, bias, dst, psum, psq, nullptr, pb,
+                                      gca_xcd_remap((int)blockIdx.x - nA, (int)gridDim.x - nA), As_, Bs_, taptab);
+  }
+}
+
 // Split-K finishing pass, grid (channels, parts): sum the slabs in fixed order, add bias, (+=) store in
 // NCDHW (through the class's destination map), and emit the BN partial sums [K][parts].
 constexpr int FINISH_CHUNK = 4096;
@@ -625,7 +662,7 @@ inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, 
 }
 
 // ---- launch configuration ------------------------------------------------------------------
-struct IgemmCfg { int bm; int bn; int splits; int kt_per_split; };
+struct IgemmCfg { int bm; int bn; int splits; int kt_per_split; int tail_bm; int main_cols; };
 
 inline int pack_rows(int M) { return (int)gca_round_up(M, 32) + 128; }   // every tile height up to 160 stays in bounds
 
@@ -634,7 +671,7 @@ inline int pack_rows(int M) { return (int)gca_round_up(M, 32) + 128; }   // ever
 // gathers for pointwise-in-space classes; the K loop is split when the tile grid cannot occupy the CUs and
 // the partial slabs stay small.  tune code: rows | 1024 for the 256-column variant.
 inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force_bm, int force_splits) {
-  IgemmCfg best{64, 128, 1, nk};
+  IgemmCfg best{64, 128, 1, nk, 0, 0};
   double best_cost = 1e300;
   const bool force_vec = force_bm >= 1024;
   const int force_rows = force_bm & 1023;
@@ -664,22 +701,31 @@ inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force
       const double eff = (0.55 + 0.1 * tm) * (v ? 1.15 : 1.0) * occ;
       const double work = (double)bm * bn * per;
       const double cost = rounds * work / eff + (s > 1 ? 0.05 * rounds * work + 8.0 * bm * bn : 0.0);
-      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per}; }
+      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0}; }
     }
   }
   return best;
 }
 
-inline void tune_of(const gca_conv_geom* g, int which, int& fbm, int& fs) {
-  if (which == 0) { fbm = g->tune_fwd_bm; fs = g->tune_fwd_splits; }
-  else { fbm = g->tune_dgrad_bm; fs = g->tune_dgrad_splits; }
+inline void tune_of(const gca_conv_geom* g, int which, int& fbm, int& fs, int& tail) {
+  if (which == 0) { fbm = g->tune_fwd_bm; fs = g->tune_fwd_splits; tail = g->tune_fwd_tail; }
+  else { fbm = g->tune_dgrad_bm; fs = g->tune_dgrad_splits; tail = g->tune_dgrad_tail; }
 }
 
 inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, const IgemmParams& p, size_t nclasses) {
-  int fbm, fs;
-  tune_of(g, which, fbm, fs);
-  (void)nclasses;                                   // strided dgrad: one setting for all classes
-  return choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
+  int fbm, fs, tail;
+  tune_of(g, which, fbm, fs, tail);
+  IgemmCfg cf = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
+  // Two-phase launch (measured configurations only; single-class passes, 128-column tiles, no split-K): the first
+  // `main_cols` column tiles run with the tall tile, the rest with a short one -- the last, partly filled wave of tall
+  // workgroups (up to a quarter of the launch time on the layer-1 shapes) becomes a full wave of short ones.
+  // tail code = short tile rows/32 | main column tiles << 8.
+  if (tail > 0 && nclasses == 1 && cf.splits == 1 && cf.bn == 128) {
+    const int tb = (tail & 255) * 32, mc = tail >> 8;
+    const long long tilesN = gca_ceil_div(p.Ntot, 128);
+    if (tb >= 32 && tb < cf.bm && mc > 0 && mc < tilesN) { cf.tail_bm = tb; cf.main_cols = mc; }
+  }
+  return cf;
 }
 
 template <int TM, int BN, int FAST, bool VEC>
@@ -704,26 +750,58 @@ inline int stat_parts(const IgemmCfg& c, long long Ntot) {
   return (int)gca_ceil_div(Ntot, c.bn);
 }
 
-int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack, const int2* table, const float* bias,
-              float* dst, float* psum, float* psq, float* slab, IgemmParams p, hipStream_t st) {
-  p.tilesM = (int)gca_ceil_div(p.DK, c.bm);
-  p.tilesN = (int)gca_ceil_div(p.Ntot, c.bn);
-  p.splits = c.splits; p.kt_per_split = c.kt_per_split;
-  p.P = stat_parts(c, p.Ntot);
-  if (c.splits > 1 && !slab) return GCA_EINVAL;
-  const long long nblk = (long long)p.tilesM * p.tilesN * c.splits;
-  if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
-  dim3 grid((unsigned)nblk);
-  float* ps = c.splits > 1 ? nullptr : psum;
-  float* pq = c.splits > 1 ? nullptr : psq;
-  switch (c.bm / 32) {
+int launch_tiles(int bm, const IgemmCfg& c, int fast, dim3 grid, hipStream_t st, const float* src, const float* apack,
+                 const int2* table, const float* bias, float* dst, float* ps, float* pq, float* slab, const IgemmParams& p) {
+  switch (bm / 32) {
     case 1: launch_tm<1>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
     case 2: launch_tm<2>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
     case 3: launch_tm<3>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
     case 4: launch_tm<4>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
     default: launch_tm<5>(c, fast, grid, st, src, apack, table, bias, dst, ps, pq, slab, p); break;
   }
-  int rc = gca_launch_status();
+  return gca_launch_status();
+}
+
+int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack, const int2* table, const float* bias,
+              float* dst, float* psum, float* psq, float* slab, IgemmParams p, hipStream_t st) {
+  const int tilesN = (int)gca_ceil_div(p.Ntot, c.bn);
+  p.splits = c.splits; p.kt_per_split = c.kt_per_split;
+  p.P = stat_parts(c, p.Ntot);
+  if (c.splits > 1 && !slab) return GCA_EINVAL;
+  float* ps = c.splits > 1 ? nullptr : psum;
+  float* pq = c.splits > 1 ? nullptr : psq;
+  if (c.tail_bm > 0) {                       // two-phase: tall tiles over [0, main_cols), short tiles over the rest
+    if ((fast == 1 || fast == 2) && c.tail_bm <= 64) {          // one launch (conv_igemm_2phase_kernel)
+      p.tilesM = (int)gca_ceil_div(p.DK, c.bm); p.tilesN = c.main_cols; p.tileN_off = 0;
+      const int tmB = (int)gca_ceil_div(p.DK, c.tail_bm), tnB = tilesN - c.main_cols;
+      const long long nA = (long long)p.tilesM * p.tilesN, nB = (long long)tmB * tnB;
+      if (nA + nB > 0x7fffffffLL) return GCA_EINVAL;
+      bool done = true;
+#define GCA_2P(A, B)                                                                                                          \
+  if (c.bm == 32 * A && c.tail_bm == 32 * B) {                                                                                \
+    if (fast == 1) hipLaunchKernelGGL((conv_igemm_2phase_kernel<A, B, 1>), dim3((unsigned)(nA + nB)), dim3(256), 0, st, src,  \
+                                      apack, table, bias, dst, ps, pq, p, (int)nA, tmB, tnB);                                \
+    else hipLaunchKernelGGL((conv_igemm_2phase_kernel<A, B, 2>), dim3((unsigned)(nA + nB)), dim3(256), 0, st, src, apack,     \
+                            table, bias, dst, ps, pq, p, (int)nA, tmB, tnB);                                                 \
+  } else
+      GCA_2P(2, 1) GCA_2P(3, 1) GCA_2P(3, 2) GCA_2P(4, 1) GCA_2P(4, 2) GCA_2P(5, 1) GCA_2P(5, 2) { done = false; }
+#undef GCA_2P
+      if (done) return gca_launch_status();
+    }
+    p.tilesM = (int)gca_ceil_div(p.DK, c.bm); p.tilesN = c.main_cols; p.tileN_off = 0;
+    int rc = launch_tiles(c.bm, c, fast, dim3((unsigned)((long long)p.tilesM * p.tilesN)), st, src, apack, table, bias, dst, ps, pq,
+                          slab, p);
+    if (rc) return rc;
+    p.tilesM = (int)gca_ceil_div(p.DK, c.tail_bm); p.tilesN = tilesN - c.main_cols; p.tileN_off = c.main_cols;
+    return launch_tiles(c.tail_bm, c, fast, dim3((unsigned)((long long)p.tilesM * p.tilesN)), st, src, apack, table, bias, dst, ps,
+                        pq, slab, p);
+  }
+  p.tilesM = (int)gca_ceil_div(p.DK, c.bm);
+  p.tilesN = tilesN;
+  p.tileN_off = 0;
+  const long long nblk = (long long)p.tilesM * p.tilesN * c.splits;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
+  int rc = launch_tiles(c.bm, c, fast, dim3((unsigned)nblk), st, src, apack, table, bias, dst, ps, pq, slab, p);
   if (rc || c.splits == 1) return rc;
   hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits,
                      bias, dst, psum, psq, p);
@@ -751,7 +829,7 @@ int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
 
 extern "C" {
 
-int gca_version(void) { return 5; }
+int gca_version(void) { return 6; }
 
 int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return GCA_EINVAL;

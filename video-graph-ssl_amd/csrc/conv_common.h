@@ -60,6 +60,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && (v >> 10) <= 1)) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
   if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 10) return false;
+  for (int v : {g->tune_fwd_tail, g->tune_dgrad_tail}) if (v < 0 || (v != 0 && ((v & 255) < 1 || (v & 255) > 4))) return false;
   return true;
 }
 

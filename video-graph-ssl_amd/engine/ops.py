@@ -188,51 +188,83 @@ class ConvPlan:
         hit = _TUNE_CACHE.get(key)
         if hit is not None:
             if which == 0:
-                g.tune_fwd_bm, g.tune_fwd_splits = hit
+                g.tune_fwd_bm, g.tune_fwd_splits = hit[0], hit[1]
+                g.tune_fwd_tail = hit[2] if len(hit) > 2 else 0
             elif which == 1:
-                g.tune_dgrad_bm, g.tune_dgrad_splits = hit
+                g.tune_dgrad_bm, g.tune_dgrad_splits = hit[0], hit[1]
+                g.tune_dgrad_tail = hit[2] if len(hit) > 2 else 0
             else:
                 g.tune_wgrad_tile, g.tune_wgrad_splits = hit
             if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0:      # still a valid launch code for this library
                 self.refresh()
                 return
             g.tune_fwd_bm = g.tune_fwd_splits = g.tune_dgrad_bm = g.tune_dgrad_splits = 0
-            g.tune_wgrad_tile = g.tune_wgrad_splits = 0
+            g.tune_wgrad_tile = g.tune_wgrad_splits = g.tune_fwd_tail = g.tune_dgrad_tail = 0
         if which == 0:
             cands = self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)
         elif which == 1:
             cands = self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)
         else:
             cands = self._wgrad_candidates(K, g.C * self.taps, -(-(N * OD * OH * OW) // 32))
-        best, best_t = None, None
-        for c in cands:
+        def apply(c):
             if which == 0:
-                g.tune_fwd_bm, g.tune_fwd_splits = c
+                g.tune_fwd_bm, g.tune_fwd_splits = c[0], c[1]
+                g.tune_fwd_tail = c[2] if len(c) > 2 else 0
             elif which == 1:
-                g.tune_dgrad_bm, g.tune_dgrad_splits = c
+                g.tune_dgrad_bm, g.tune_dgrad_splits = c[0], c[1]
+                g.tune_dgrad_tail = c[2] if len(c) > 2 else 0
             else:
                 g.tune_wgrad_tile, g.tune_wgrad_splits = c
             self.refresh()
+
+        def measure(c):
+            apply(c)
             if which == 2 and self.cfg(2)[3] & 255 != c[0]:      # shape not available for this tap count
-                continue
+                return None
             try:
-                t = _time_ms(run)
+                return _time_ms(run)
             except RuntimeError:
-                continue
-            if best_t is None or t < best_t:
-                best, best_t = c, t
+                return None
+
+        timed = []
+        for c in cands:
+            t = measure(c)
+            if t is not None:
+                timed.append((t, tuple(c)))
+        timed.sort()
+        if which < 2 and timed:
+            # two-phase launches on the fastest single-launch shapes: tall tiles for the full waves of workgroups, short
+            # tiles for the remainder (how many workgroups run at once is not known here, so a few guesses are measured)
+            M, Ntot = (K, N * OD * OH * OW) if which == 0 else (g.C, g.N * g.D * g.H * g.W)
+            single_class = which == 0 or (g.sd == 1 and g.sh == 1 and g.sw == 1)
+            tilesN = -(-Ntot // 128)
+            for _, base in list(timed[:2]):
+                bm, sp = base[0], base[1]
+                if not single_class or sp != 1 or bm >= 1024 or bm <= 32:
+                    continue
+                tilesM = -(-M // bm)
+                seen = set()
+                for slots in (512, 768, 1024, 1280):
+                    full = (tilesM * tilesN // slots) * slots
+                    main_cols = full // tilesM
+                    if main_cols <= 0 or main_cols >= tilesN or main_cols in seen:
+                        continue
+                    seen.add(main_cols)
+                    for tail_rows in (32, 64):
+                        if tail_rows >= bm:
+                            continue
+                        c = (bm, 1, (tail_rows // 32) | (main_cols << 8))
+                        t = measure(c)
+                        if t is not None:
+                            timed.append((t, c))
+            timed.sort()
+        best = timed[0][1] if timed else None
         if best is not None:
             _TUNE_CACHE[key] = tuple(int(v) for v in best)
             _TUNE_DIRTY[0] = True
-            if which == 0:
-                g.tune_fwd_bm, g.tune_fwd_splits = best
-            elif which == 1:
-                g.tune_dgrad_bm, g.tune_dgrad_splits = best
-            else:
-                g.tune_wgrad_tile, g.tune_wgrad_splits = best
-        elif which == 2:
-            g.tune_wgrad_tile, g.tune_wgrad_splits = 0, 0
-        self.refresh()
+            apply(best)
+        else:
+            apply((0, 0, 0) if which < 2 else (0, 0))
 
 
 @functools.lru_cache(maxsize=None)
