@@ -27,6 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec)
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak; a bf16x3 / bf16x6 product costs 3 / 6 of them
 FWD_GFLOP_PER_VIEW = 16.953       # R(2+1)D-18 @16x112x112, conv+linear, 2*MAC
 
 
@@ -49,6 +50,12 @@ def parse():
     ap.add_argument('--backbone', default='R2P1D18')
     ap.add_argument('--queue', type=int, default=0, help='0 = 4096 at N=1, 65536 at N>1 (BASELINE configs 2/3)')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--math', default='bf16x3', choices=['bf16x3', 'bf16x6', 'f32'],
+                    help="conv arithmetic (include/gca_hip.h gca_set_conv_math): bf16x3 = fp32 operands split into bf16 "
+                         "hi+lo, three bf16 MFMAs per product, fp32 accumulate (4.5e-6 rel. error vs fp32 MFMA, measured); "
+                         "bf16x6 = hi+mid+lo, six products, fp32-grade; f32 = fp32 MFMA.  The other modes are timed too and "
+                         "reported beside the headline value")
+    ap.add_argument('--no-other-math', action='store_true', help='skip timing the other arithmetic modes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--layer-table', action='store_true', help='log per-layer conv kernel timings to stderr')
@@ -107,7 +114,15 @@ def conv_layers_of(model, x_shape, pkg):
 def _sym(c):
     """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10}."""
     vec, fast = c[1] == 256, (c[3] >> 8) & 3       # bit 10 only says the class COULD use float4 gathers
-    return 'conv_igemm_kernel<%d,%d,%d,%s>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false')
+    return 'conv_igemm_kernel<%d,%d,%d,%s,%d>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false', _MATH[0])
+
+
+_MATH = [0]          # conv arithmetic of the kernels being timed: 0 fp32 MFMA, 1 bf16x3, 2 bf16x6 (set in main from --math)
+DTYPE = {'f32': 'f32',
+         'bf16x6': 'bf16x6 (fp32 tensors; conv products as 6 bf16 MFMAs on hi/mid/lo splits = fp32-grade, fp32 accumulate; '
+                   'everything else fp32)',
+         'bf16x3': 'bf16x3 (fp32 tensors; conv products as 3 bf16 MFMAs on hi/lo splits, 2^-17 relative, fp32 accumulate; '
+                   'everything else fp32)'}
 
 
 def kernel_timing(pkg, trainer, args):
@@ -126,10 +141,11 @@ def kernel_timing(pkg, trainer, args):
             layers.append((Lin(m.out_features, (1, 1, 1), (1, 1, 1), (0, 0, 0), m.weight), (b, m.in_features, 1, 1, 1), 0))
     sym = {}
 
-    def add(name, ms, flops, times, launches=1):
+    def add(name, ms, flops, times, launches=1, nbytes=0.0):
         # `launches`: kernel launches behind one call (a strided dgrad is one launch per stride-residue class)
-        e = sym.setdefault(name, [0.0, 0.0, 0])
-        e[0] += ms * times; e[1] += flops * times; e[2] += times * launches
+        # `nbytes`: algorithmic HBM bytes of the call = every operand read once + the result written once
+        e = sym.setdefault(name, [0.0, 0.0, 0, 0.0])
+        e[0] += ms * times; e[1] += flops * times; e[2] += times * launches; e[3] += nbytes * times
 
     dev = torch.device('cuda', torch.cuda.current_device())
     for i, (m, shp, xs) in enumerate(layers):
@@ -146,15 +162,16 @@ def kernel_timing(pkg, trainer, args):
         t = ev_time_ms(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5, 1)
         t_f, t_d = t, None
         c0 = plan.cfg(0)
-        add(_sym(c0), t, flops, 2)   # key + query forward
+        nbytes = 4.0 * (x.numel() + dy.numel() + w.numel())
+        add(_sym(c0), t, flops, 2, 1, nbytes)   # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
             # (the head's first Linear does: its input is the encoder feature)
             t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
             c1 = plan.cfg(1)
-            add(_sym(c1), t, flops, 1, max(1, c1[3] & 255))
+            add(_sym(c1), t, flops, 1, max(1, c1[3] & 255), nbytes)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         cw = plan.cfg(2)
-        add('conv_wgrad_kernel<%dx%d>' % (cw[0], cw[1]), t, flops, 1)
+        add('conv_wgrad_kernel<%dx%d>' % (cw[0], cw[1]), t, flops, 1, 1, nbytes)
         if args.layer_table:
             log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%s/%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
                 % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, plan.cfg(0)[:3], plan.cfg(1)[:3] if i > 0 else '-',
@@ -162,13 +179,29 @@ def kernel_timing(pkg, trainer, args):
                    ('%7.3f ms %6.1f TF' % (t_d, flops / 1e9 / t_d)) if t_d else '      --       ', t, flops / 1e9 / t))
         del x, dy, dx
     table = {k: dict(ms_per_step=round(v[0], 4), gflop_per_step=round(v[1] / 1e9, 2), launches_per_step=v[2],
-                     tflops=round((v[1] / 1e12) / (v[0] / 1e3), 3)) for k, v in sym.items()}
+                     tflops=round((v[1] / 1e12) / (v[0] / 1e3), 3), algorithmic_GBps=round(v[3] / 1e9 / (v[0] / 1e3), 1))
+             for k, v in sym.items()}
     dom = max(sym, key=lambda k: sym[k][0])
     ach = table[dom]['tflops']
-    roof = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=pmc_traffic(dom),
-                avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4), launches_per_step=sym[dom][2],
-                flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1))
+    common = dict(kernel=dom, traffic=pmc_traffic(dom), avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4),
+                  launches_per_step=sym[dom][2], flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1),
+                  algorithmic_bytes_per_launch_avg=round(sym[dom][3] / sym[dom][2], 1))
+    nprod = {0: 1, 1: 3, 2: 6}[_MATH[0]]
+    if _MATH[0] == 0:
+        roof = dict(bound='mfma', achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                    frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common)
+    else:
+        # bf16x3 / bf16x6: 3 / 6 bf16 MFMAs per product -> matrix ceiling 2500/3 (/6) TFLOP/s of conv FLOPs.  The roofline
+        # of the kernel is min(that, arithmetic intensity x HBM peak); report against whichever binds.
+        mfma_peak = PEAK_BF16_MFMA_TFLOPS / nprod
+        ai = sym[dom][1] / sym[dom][3]                      # FLOP per algorithmic byte
+        if ai * PEAK_HBM_GBPS / 1e3 < mfma_peak:
+            gbps = table[dom]['algorithmic_GBps']
+            roof = dict(bound='hbm', achieved=gbps, peak=PEAK_HBM_GBPS, unit='GB/s', frac=round(gbps / PEAK_HBM_GBPS, 4),
+                        flop_per_byte=round(ai, 1), mfma_frac=round(ach / mfma_peak, 4), tflops=ach, **common)
+        else:
+            roof = dict(bound='mfma', achieved=ach, peak=round(mfma_peak, 1), unit='TFLOP/s', frac=round(ach / mfma_peak, 4),
+                        flop_per_byte=round(ai, 1), note='peak = dense bf16 MFMA 2500 TFLOP/s / %d products' % nprod, **common)
     return roof, table
 
 
@@ -272,7 +305,7 @@ def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
     gt = graph_timing(pkg, bsz, 192, 8, size // 8)
     res = {'metric': 'pretrain_clips_per_sec', 'value': round(bsz * world * args.steps / dt, 3), 'unit': 'clips/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.math], 'data': 'synthetic',
            'config': {'workload': 'SimSiam pre-training iteration, S3D + temporal-graph blocks (base.5/9/14), 16-frame %dx%d '
                                   'clips, %d clips/GPU, FEAT_DIM 1024, predictor MLP, SGD (BASELINE.json configs[3])' % (size, size, bsz),
                       'global_batch': bsz * world, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph},
@@ -384,6 +417,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pkg.engine.ops.set_conv_math(args.math)
+    _MATH[0] = pkg.engine.ops.CONV_MATH[args.math]
     if args.workload == 'simsiam':
         return simsiam_main(args, pkg, dev, ctx, world, rank, barrier)
     K = args.queue or (4096 if world == 1 else 65536)
@@ -425,7 +460,7 @@ def main():
     res = {
         'metric': 'pretrain_clips_per_sec', 'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.math], 'data': 'synthetic',
         'config': {'workload': 'MoCo pre-training iteration, %s, %d-frame %dx%d clips, %d clips/GPU (global %d), '
                                'queue K=%d, T=0.07, SGD+EMA (BASELINE.json configs[%d])'
                                % (args.backbone, args.frames, args.size, args.size, args.batch, global_batch, K,
@@ -443,6 +478,33 @@ def main():
     if not args.no_kernel_timing:
         res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
         log('kernel timing done')
+    if world == 1 and not args.no_other_math:
+        # the same workload in the other arithmetic modes (own trainer, own tuned plans), timed the same way
+        del tr
+        import gc
+        for other in [m for m in ('f32', 'bf16x6', 'bf16x3') if m != args.math]:
+            gc.collect()
+            pkg.engine.ops.set_conv_math(other)
+            _MATH[0] = pkg.engine.ops.CONV_MATH[other]
+            tr2 = pkg.MoCoTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
+            for _ in range(max(args.warmup, 0) + 3):
+                tr2.train_step(images)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out2 = tr2.train_step(images)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            key = 'math_' + other
+            res[key] = {'value': round(args.batch * args.steps / dt2, 3), 'unit': 'clips/s', 'dtype': DTYPE[other],
+                        'ms_per_step': round(dt2 / args.steps * 1e3, 3), 'final_loss': round(float(out2['loss'].item()), 5)}
+            if not args.no_kernel_timing:
+                res[key]['roofline'], _ = kernel_timing(pkg, tr2, args)
+            log('arithmetic mode %s timed' % other)
+            del tr2
+        gc.collect()
+        pkg.engine.ops.set_conv_math(args.math)
+        _MATH[0] = pkg.engine.ops.CONV_MATH[args.math]
     if world == 1:
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, K)

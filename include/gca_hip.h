@@ -31,6 +31,19 @@ extern "C" {
 
 int gca_version(void);
 
+/* Arithmetic of the convolution kernels (forward, dgrad, wgrad; tensors stay fp32 in HBM in every mode):
+ *   0  f32:     v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (157 TFLOP/s peak)
+ *   1  bf16x3:  every fp32 operand is split in the kernel into hi = bf16(x), lo = bf16(x - hi); a product becomes
+ *               hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-17 relative error per
+ *               product (16+ of fp32's 24 significand bits; TF32 -- the reference's default on its own GPUs,
+ *               torch.backends.cudnn.allow_tf32 -- keeps 11), 5.3x less matrix-pipe time than mode 0.
+ *   2  bf16x6:  three parts (x = hi + mid + lo to 2^-27) and the six products hh, hm, mh, hl, lh, mm: the dropped terms
+ *               are <= 2^-25 relative, below fp32's own rounding -- fp32-grade results (same parity bars as mode 0 in
+ *               tests/) at 2.7x less matrix-pipe time.
+ * The default comes from the environment (GCA_CONV_MATH=f32|bf16x3|bf16x6, unset = f32).  GCA_EINVAL for another mode. */
+int gca_set_conv_math(int mode);
+int gca_get_conv_math(void);
+
 /* ---------------------------------------------------------------------------------------
  * 3D convolution as an MFMA (v_mfma_f32_32x32x2_f32) implicit GEMM, NCDHW, no bias.
  * Replaces every nn.Conv3d on the path: resnet2p1d.py:13-36,162-174; s3d_1.py:40,53,57;

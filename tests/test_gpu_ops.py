@@ -19,6 +19,16 @@ def ops(pkg):
     return pkg.engine.ops
 
 
+@pytest.fixture(params=['f32', 'bf16x6', 'bf16x3'])
+def ctol(request, ops):
+    """Runs a conv test under every arithmetic mode of the kernels (gca_set_conv_math) and hands it the bar that mode is
+    held to: 1e-5 for fp32 MFMA and for bf16x6 (fp32-grade split products; measured 0.3-1e-6 rms against fp32 MFMA),
+    5e-5 for bf16x3 (measured 4-6e-6) -- all far inside north_star's 1e-3."""
+    ops.set_conv_math(request.param)
+    yield 5e-5 if request.param == 'bf16x3' else 1e-5
+    ops.set_conv_math('f32')
+
+
 def _conv_all(ops, x, w, dy, k, s, p):
     plan = ops.conv_plan(tuple(x.shape), w.shape[0], k, s, p, x.device)
     y, (ss, sq) = ops.conv_fwd(plan, x, ops.conv_pack(plan, 0, w), None, stats=True)
@@ -29,15 +39,15 @@ def _conv_all(ops, x, w, dy, k, s, p):
 
 
 @pytest.mark.parametrize('name', CONVS)
-def test_conv_golden(ops, golden, name):
+def test_conv_golden(ops, golden, ctol, name):
     g = golden('ops')
     cfg = g.t(name + ':cfg').tolist()
     x, w, dy = (g.t(name + ':' + t).to(DEV) for t in ('x', 'w', 'dy'))
     y, dx, dw, s1, s2 = _conv_all(ops, x, w, dy, cfg[0:3], cfg[3:6], cfg[6:9])
     yr = g.t(name + ':y')
-    assert rel_err(y, yr) < 1e-5
-    assert rel_err(dx, g.t(name + ':dx')) < 1e-5
-    assert rel_err(dw, g.t(name + ':dw')) < 1e-5
+    assert rel_err(y, yr) < ctol
+    assert rel_err(dx, g.t(name + ':dx')) < ctol
+    assert rel_err(dw, g.t(name + ':dw')) < ctol
     # fused BN statistics from the conv epilogue
     assert rel_err(s1, yr.sum((0, 2, 3, 4))) < 1e-4
     assert rel_err(s2, (yr * yr).sum((0, 2, 3, 4))) < 1e-4
@@ -50,7 +60,7 @@ def test_conv_golden(ops, golden, name):
     ((4, 16, 1, 1, 1), 24, (1, 1, 1), (1, 1, 1), (0, 0, 0)),        # a Linear layer
     ((2, 7, 5, 6, 7), 9, (3, 3, 3), (1, 2, 1), (1, 0, 2)),          # mixed stride / asymmetric padding
 ])
-def test_conv_random_vs_aten(ops, shape, K, k, s, p):
+def test_conv_random_vs_aten(ops, ctol, shape, K, k, s, p):
     torch.manual_seed(0)
     x = torch.randn(shape)
     w = torch.randn((K, shape[1]) + tuple(k)) * 0.1
@@ -60,9 +70,9 @@ def test_conv_random_vs_aten(ops, shape, K, k, s, p):
     dy = torch.randn_like(yr)
     yr.backward(dy)
     y, dx, dw, _, _ = _conv_all(ops, x.to(DEV), w.to(DEV), dy.to(DEV), k, s, p)
-    assert rel_err(y, yr) < 1e-5
-    assert rel_err(dx, xr.grad) < 1e-5
-    assert rel_err(dw, wr.grad) < 1e-5
+    assert rel_err(y, yr) < ctol
+    assert rel_err(dx, xr.grad) < ctol
+    assert rel_err(dw, wr.grad) < ctol
 
 
 @pytest.mark.parametrize('shape,K,k,s,p', [
@@ -71,7 +81,7 @@ def test_conv_random_vs_aten(ops, shape, K, k, s, p):
     ((2, 20, 3, 12, 12), 100, (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # spatial window, strided (4 dgrad classes)
     ((2, 33, 1, 1, 1), 170, (1, 1, 1), (1, 1, 1), (0, 0, 0)),       # Linear
 ])
-def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
+def test_conv_every_launch_configuration(ops, ctol, shape, K, k, s, p):
     """Force every tile height (32..160), the 256-column float4 variant, and split-K factors through the
     tune_* fields: all must give the same convolution (the autotuner may pick any of them)."""
     torch.manual_seed(0)
@@ -96,9 +106,9 @@ def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
             dx = ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd))
             dw = torch.zeros_like(wd)
             ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
-            assert rel_err(y, yr) < 1e-5, (code, sp, plan.cfg(0))
-            assert rel_err(dx, xr.grad) < 1e-5, (code, sp, plan.cfg(1))
-            assert rel_err(dw, wr.grad) < 1e-5, (code, sp)
+            assert rel_err(y, yr) < ctol, (code, sp, plan.cfg(0))
+            assert rel_err(dx, xr.grad) < ctol, (code, sp, plan.cfg(1))
+            assert rel_err(dw, wr.grad) < ctol, (code, sp)
             assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4
             assert rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-4
     assert len(seen) >= 8
@@ -117,10 +127,10 @@ def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
                 plan.refresh()
                 if which == 0:
                     y, (ss, sq) = ops.conv_fwd(plan, xd, ops.conv_pack(plan, 0, wd), None, stats=True)
-                    assert rel_err(y, yr) < 1e-5, (bm, tail, mc)
+                    assert rel_err(y, yr) < ctol, (bm, tail, mc)
                     assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4 and rel_err(sq.sum(1), (yr.detach() ** 2).sum((0, 2, 3, 4))) < 1e-4
                 else:
-                    assert rel_err(ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd)), xr.grad) < 1e-5, (bm, tail, mc)
+                    assert rel_err(ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd)), xr.grad) < ctol, (bm, tail, mc)
     plan.g.tune_fwd_tail = plan.g.tune_dgrad_tail = 0
     # every wgrad tile shape (1..10; shapes not built for this tap count fall back to the heuristic one)
     seen_w = set()
@@ -131,7 +141,7 @@ def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
             seen_w.add(plan.cfg(2)[:2])
             dw = torch.zeros_like(wd)
             ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
-            assert rel_err(dw, wr.grad) < 1e-5, (idx, sp, plan.cfg(2))
+            assert rel_err(dw, wr.grad) < ctol, (idx, sp, plan.cfg(2))
     assert len(seen_w) >= 6
 
 
@@ -140,7 +150,7 @@ def test_conv_every_launch_configuration(ops, shape, K, k, s, p):
     ((1, 2, 9, 9, 9), 5, (7, 7, 7), (1, 2, 2), (3, 3, 3)),          # 343 taps: per-element window tests (3D-ResNet stem)
     ((2, 6, 5, 7, 7), 10, (3, 3, 3), (1, 1, 1), (1, 1, 1)),         # 27 taps, all three axes padded
 ])
-def test_conv_wgrad_tap_mask_kinds(ops, shape, K, k, s, p):
+def test_conv_wgrad_tap_mask_kinds(ops, ctol, shape, K, k, s, p):
     torch.manual_seed(3)
     x = torch.randn(shape)
     w = torch.randn((K, shape[1]) + tuple(k)) * 0.1
@@ -155,7 +165,7 @@ def test_conv_wgrad_tap_mask_kinds(ops, shape, K, k, s, p):
         plan.refresh()
         dw = torch.zeros_like(w).to(DEV)
         ops.conv_wgrad(plan, x.to(DEV), dy.to(DEV), dw, accumulate=True)
-        assert rel_err(dw, wr.grad) < 1e-5, (idx, plan.cfg(2))
+        assert rel_err(dw, wr.grad) < ctol, (idx, plan.cfg(2))
 
 
 def test_conv_batch_stride_views(ops):
@@ -537,7 +547,7 @@ def test_autotuner_pins_a_valid_configuration(ops):
     ((32, 230, 8, 14, 14), 128, (3, 1, 1), (2, 1, 1), (1, 0, 0)),      # layer2 strided temporal conv
     ((32, 512, 1, 4, 4), 1152, (1, 3, 3), (1, 1, 1), (0, 1, 1)),       # layer4 (split-K territory)
 ])
-def test_conv_full_size_vs_device_reference_and_linearity(ops, shape, K, k, s, p):
+def test_conv_full_size_vs_device_reference_and_linearity(ops, ctol, shape, K, k, s, p):
     """BASELINE-size layers (too big for the CPU oracle in test time): all three passes against ATen's own fp32
     convolution on the same GPU (MIOpen; a different algorithm and summation order, hence 2e-4), plus a
     size-independent property of the product kernels alone: linearity in the input."""
@@ -560,7 +570,7 @@ def test_conv_full_size_vs_device_reference_and_linearity(ops, shape, K, k, s, p
     assert rel_err(dw, wr.grad) < 2e-4
     x2 = torch.randn(shape, device=DEV)
     lin = ops.conv_fwd(plan, 0.5 * x - 2.0 * x2, wp0)
-    assert rel_err(lin, 0.5 * y - 2.0 * ops.conv_fwd(plan, x2, wp0)) < 1e-5
+    assert rel_err(lin, 0.5 * y - 2.0 * ops.conv_fwd(plan, x2, wp0)) < 2 * ctol
 
 
 @pytest.mark.parametrize('N,C,SP,res', [(4, 10, 48, True), (3, 7, 30, False), (2, 5, 20000, True), (8, 6, 1, False)])

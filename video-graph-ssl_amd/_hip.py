@@ -42,6 +42,8 @@ _GP, _PP = C.POINTER(ConvGeom), C.POINTER(PoolGeom)
 # name -> (restype, argtypes): exactly the declarations of include/gca_hip.h
 SIGNATURES = {
     'gca_version': (c_i32, []),
+    'gca_set_conv_math': (c_i32, [c_i32]),
+    'gca_get_conv_math': (c_i32, []),
     'gca_conv_pack_elems': (c_i64, [_GP, c_i32]),
     'gca_conv_pack': (c_i32, [_GP, c_i32, c_vp, c_vp, c_vp]),
     'gca_conv_table_rows': (c_i64, [_GP, c_i32]),

@@ -72,10 +72,13 @@ struct IgemmParams {
 // columns, a wave covers one whole tile row per load).
 // ---------------------------------------------------------------------------------------------
 constexpr int LDK = BK + 4;     // LDS row pitch in floats (80 B)
+// pitch by arithmetic mode: a row of 16 k is 64 B as fp32 or as bf16 hi+lo pairs, 96 B as bf16 hi+mid+lo (+16 B pad each:
+// 20 r mod 64 and 28 r mod 64 both walk all 16 four-bank groups over 16 rows, so the b128 fragment reads are conflict-free)
+constexpr int lds_pitch(int math) { return math == 2 ? 28 : LDK; }
 
 // The tile body is a device function so that ONE launch can mix two tile heights (conv_igemm_2phase_kernel below):
 // `bid` is the workgroup's logical id inside its phase, As_/Bs_/taptab the workgroup's LDS (sized by the caller).
-template <int TM, int BN, int FAST, bool VEC>
+template <int TM, int BN, int FAST, bool VEC, int MATH>
 __device__ __forceinline__ void igemm_tile(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
@@ -87,8 +90,9 @@ __device__ __forceinline__ void igemm_tile(
   static_assert(!VEC || (BN == 256 && FAST == 1), "VEC variant: 256 columns, <= 32-tap mask path");
   static_assert(BN == 128 || BN == 256, "BN");
 
-  float (*As)[BM][LDK] = reinterpret_cast<float (*)[BM][LDK]>(As_);          // [2][BM][LDK]
-  float (*Bs)[BN][LDK] = reinterpret_cast<float (*)[BN][LDK]>(Bs_);          // [2][BN][LDK]
+  constexpr int LDP = lds_pitch(MATH), NP = math_parts(MATH);                // row pitch (floats), bf16 parts per element
+  float (*As)[BM][LDP] = reinterpret_cast<float (*)[BM][LDP]>(As_);          // [2][BM][LDP]
+  float (*Bs)[BN][LDP] = reinterpret_cast<float (*)[BN][LDP]>(Bs_);          // [2][BN][LDP]
 
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int split = bid % p.splits; bid /= p.splits;
@@ -201,11 +205,15 @@ __device__ __forceinline__ void igemm_tile(
   };
   // piece g of the next tile's fetch, placed after MFMA group g (G groups per tile): table rows + A tile
   // first, then the gathers spread over the following groups, leaving the last group(s) as latency shadow
-  constexpr int G = 2 * TM * TN;
+  constexpr int G = (MATH ? 1 : 2) * TM * TN;
   constexpr int GSPAN = G > 2 ? G - 2 : 1;                              // groups 1..GSPAN carry the gathers
   constexpr int GCHUNK = (B_PER + GSPAN - 1) / GSPAN;
   auto issue_piece = [&](int g, int kt) __attribute__((always_inline)) {
-    if (g == 0) { issue_table(kt); issue_a(kt); }
+    if (G == 1) {
+      issue_table(kt); issue_a(kt);
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) issue_gather(i);
+    } else if (g == 0) { issue_table(kt); issue_a(kt); }
     else if (g <= GSPAN) {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i)
@@ -218,7 +226,61 @@ __device__ __forceinline__ void igemm_tile(
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) issue_gather(i);
   };
+  // MATH >= 1: every fp32 operand x is stored as bf16 parts -- bf16x3: hi = bf16(x), lo = bf16(x - hi); bf16x6: hi, mid, lo
+  // (x = hi + mid + lo to 2^-27).  A row of 16 k is two 8-k groups [hi x8 | (mid x8 |) lo x8]: the 16-byte operands that a
+  // lane of half h feeds to v_mfma_f32_32x32x16_bf16 sit at float index 4*NP*h + {0, 4, (8)} of the row.
+  auto store_split4 = [&](float* row, int chunk, float4 v) __attribute__((always_inline)) {     // k = 4*chunk .. +3 of `row`
+    float* d = row + (chunk >> 1) * (4 * NP) + (chunk & 1) * 2;
+    if (MATH == 2) {
+      uint2 h, m, l;
+      split_bf16x3(v.x, v.y, h.x, m.x, l.x);
+      split_bf16x3(v.z, v.w, h.y, m.y, l.y);
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + 4) = m;
+      *reinterpret_cast<uint2*>(d + 8) = l;
+    } else {
+      uint2 h, l;
+      split_bf16x2(v.x, v.y, h.x, l.x);
+      split_bf16x2(v.z, v.w, h.y, l.y);
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + 4) = l;
+    }
+  };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (MATH >= 1) {
+      if (A_F4 > 1 || a_last_ok) store_split4(&As[buf][a_slot(0) >> 2][0], a_slot(0) & 3, a0);
+      if (A_F4 == 2 ? a_last_ok : A_F4 > 2) store_split4(&As[buf][a_slot(1) >> 2][0], a_slot(1) & 3, a1);
+      if (A_F4 > 2 && a_last_ok) store_split4(&As[buf][a_slot(2) >> 2][0], a_slot(2) & 3, a2);
+      if (VEC) {
+        store_split4(&Bs[buf][col + 0][0], wn, make_float4(bvec[0].x, bvec[1].x, bvec[2].x, bvec[3].x));
+        store_split4(&Bs[buf][col + 1][0], wn, make_float4(bvec[0].y, bvec[1].y, bvec[2].y, bvec[3].y));
+        store_split4(&Bs[buf][col + 2][0], wn, make_float4(bvec[0].z, bvec[1].z, bvec[2].z, bvec[3].z));
+        store_split4(&Bs[buf][col + 3][0], wn, make_float4(bvec[0].w, bvec[1].w, bvec[2].w, bvec[3].w));
+      } else {          // 8 consecutive k of one column = one whole group: b128 per part
+        float* d = &Bs[buf][col][(r0 >> 3) * (4 * NP)];
+        constexpr int I1 = VEC ? 0 : 1, I2 = VEC ? 0 : 2, I3 = VEC ? 0 : 3, I4 = VEC ? 0 : 4, I5 = VEC ? 0 : 5,
+                      I6 = VEC ? 0 : 6, I7 = VEC ? 0 : 7;
+        if (MATH == 2) {
+          uint4 h, m, l;
+          split_bf16x3(breg[0], breg[I1], h.x, m.x, l.x);
+          split_bf16x3(breg[I2], breg[I3], h.y, m.y, l.y);
+          split_bf16x3(breg[I4], breg[I5], h.z, m.z, l.z);
+          split_bf16x3(breg[I6], breg[I7], h.w, m.w, l.w);
+          *reinterpret_cast<uint4*>(d) = h;
+          *reinterpret_cast<uint4*>(d + 4) = m;
+          *reinterpret_cast<uint4*>(d + 8) = l;
+        } else {
+          uint4 h, l;
+          split_bf16x2(breg[0], breg[I1], h.x, l.x);
+          split_bf16x2(breg[I2], breg[I3], h.y, l.y);
+          split_bf16x2(breg[I4], breg[I5], h.z, l.z);
+          split_bf16x2(breg[I6], breg[I7], h.w, l.w);
+          *reinterpret_cast<uint4*>(d) = h;
+          *reinterpret_cast<uint4*>(d + 4) = l;
+        }
+      }
+      return;
+    }
     if (A_F4 > 1 || a_last_ok) *reinterpret_cast<float4*>(&As[buf][a_slot(0) >> 2][(a_slot(0) & 3) * 4]) = a0;
     if (A_F4 == 2 ? a_last_ok : A_F4 > 2) *reinterpret_cast<float4*>(&As[buf][a_slot(1) >> 2][(a_slot(1) & 3) * 4]) = a1;
     if (A_F4 > 2 && a_last_ok) *reinterpret_cast<float4*>(&As[buf][a_slot(2) >> 2][(a_slot(2) & 3) * 4]) = a2;
@@ -283,7 +345,49 @@ __device__ __forceinline__ void igemm_tile(
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  if (TM <= 2 && !VEC) {
+  if constexpr (MATH >= 1) {
+    // bf16x3: x*y ~= xh*yh + xh*yl + xl*yh (the dropped xl*yl term and the rounding of the lo parts are ~2^-17 relative).
+    // bf16x6: x*y ~= hh + hm + mh + hl + lh + mm (dropped terms and part rounding <= 2^-25: fp32-grade products).
+    // fp32 accumulation in both.  One k-tile = TM*TN groups of 3 / 6 32-cycle MFMAs -- 5.3x / 2.7x less matrix-pipe time
+    // than the fp32 MFMA path's 8 x 64 cycles, so the loop is paced by the gathers and the LDS instead.
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+      float4 af[TM][NP], bf[TN][NP];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const float4*>(&As[buf][i * 32 + ll][4 * NP * lh + 4 * q]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) bf[j][q] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][4 * NP * lh + 4 * q]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
+          const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
+          if (MATH == 2) {
+            const bf16x8 xm = __builtin_bit_cast(bf16x8, af[i][1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) issue_piece(i * TN + j, kt + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  } else if (TM <= 2 && !VEC) {
     // small tiles: the loop is unrolled by two (buffers 0 / 1) and the tail peeled -- the per-tile scalar
     // bookkeeping is a visible share of an iteration that holds only 8-16 MFMAs (measured +2..+8 % here, but a
     // loss for the tall / 256-column tiles, whose bodies are already long: they keep the rolled loop below)
@@ -420,37 +524,37 @@ __device__ __forceinline__ void igemm_tile(
   }
 }
 
-template <int TM, int BN, int FAST, bool VEC>
+template <int TM, int BN, int FAST, bool VEC, int MATH>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, float* __restrict__ slab, IgemmParams p) {
-  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs_[2 * BN * LDK];
+  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TM * lds_pitch(MATH)];
+  __shared__ __attribute__((aligned(16))) float Bs_[2 * BN * lds_pitch(MATH)];
   __shared__ int taptab[64];
-  igemm_tile<TM, BN, FAST, VEC>(src, apack, table, bias, dst, psum, psq, slab, p, gca_xcd_remap(blockIdx.x, gridDim.x), As_, Bs_,
+  igemm_tile<TM, BN, FAST, VEC, MATH>(src, apack, table, bias, dst, psum, psq, slab, p, gca_xcd_remap(blockIdx.x, gridDim.x), As_, Bs_,
                                 taptab);
 }
 
 // Two tile heights in ONE launch: workgroups [0, nA) run TMA-row tiles over the first p.tilesN column tiles, the rest run
 // TMB-row tiles over the remaining ones.  Workgroups are dispatched in id order, so the short tiles flow into the CUs
 // that the last, partly filled wave of tall workgroups leaves idle (a second LAUNCH would wait for that wave to end).
-template <int TMA, int TMB, int FAST>
+template <int TMA, int TMB, int FAST, int MATH>
 __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, IgemmParams p, int nA, int tilesM_B, int tilesN_B) {
   static_assert(TMB < TMA, "the tail uses the shorter tile");
-  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TMA * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs_[2 * 128 * LDK];
+  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TMA * lds_pitch(MATH)];
+  __shared__ __attribute__((aligned(16))) float Bs_[2 * 128 * lds_pitch(MATH)];
   __shared__ int taptab[64];
   if ((int)blockIdx.x < nA) {
-    igemm_tile<TMA, 128, FAST, false>(src, apack, table, bias, dst, psum, psq, nullptr, p, gca_xcd_remap(blockIdx.x, nA), As_, Bs_, taptab);
+    igemm_tile<TMA, 128, FAST, false, MATH>(src, apack, table, bias, dst, psum, psq, nullptr, p, gca_xcd_remap(blockIdx.x, nA), As_, Bs_, taptab);
   } else {
     IgemmParams pb = p;
     pb.tileN_off = p.tileN_off + p.tilesN;
     pb.tilesM = tilesM_B; pb.tilesN = tilesN_B;
-    igemm_tile<TMB, 128, FAST, false>(src, apack, table, bias, dst, psum, psq, nullptr, pb,
+    igemm_tile<TMB, 128, FAST, false, MATH>(src, apack, table, bias, dst, psum, psq, nullptr, pb,
                                       gca_xcd_remap((int)blockIdx.x - nA, (int)gridDim.x - nA), As_, Bs_, taptab);
   }
 }
@@ -662,7 +766,7 @@ inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, 
 }
 
 // ---- launch configuration ------------------------------------------------------------------
-struct IgemmCfg { int bm; int bn; int splits; int kt_per_split; int tail_bm; int main_cols; };
+struct IgemmCfg { int bm; int bn; int splits; int kt_per_split; int tail_bm; int main_cols; int math; };
 
 inline int pack_rows(int M) { return (int)gca_round_up(M, 32) + 128; }   // every tile height up to 160 stays in bounds
 
@@ -701,7 +805,7 @@ inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force
       const double eff = (0.55 + 0.1 * tm) * (v ? 1.15 : 1.0) * occ;
       const double work = (double)bm * bn * per;
       const double cost = rounds * work / eff + (s > 1 ? 0.05 * rounds * work + 8.0 * bm * bn : 0.0);
-      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0}; }
+      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0, 0}; }
     }
   }
   return best;
@@ -716,6 +820,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
   int fbm, fs, tail;
   tune_of(g, which, fbm, fs, tail);
   IgemmCfg cf = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
+  cf.math = conv_math();
   // Two-phase launch (measured configurations only; single-class passes, 128-column tiles, no split-K): the first
   // `main_cols` column tiles run with the tall tile, the rest with a short one -- the last, partly filled wave of tall
   // workgroups (up to a quarter of the launch time on the layer-1 shapes) becomes a full wave of short ones.
@@ -729,20 +834,27 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
 }
 
 template <int TM, int BN, int FAST, bool VEC>
-void launch_one(dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
+void launch_one(int math, dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
                 float* dst, float* psum, float* psq, float* slab, const IgemmParams& p) {
-  hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC>), grid, dim3(256), 0, st, src, apack, table, bias,
-                     dst, psum, psq, slab, p);
+  if (math == 1)
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 1>), grid, dim3(256), 0, st, src, apack, table, bias,
+                       dst, psum, psq, slab, p);
+  else if (math == 2)
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 2>), grid, dim3(256), 0, st, src, apack, table, bias,
+                       dst, psum, psq, slab, p);
+  else
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 0>), grid, dim3(256), 0, st, src, apack, table, bias,
+                       dst, psum, psq, slab, p);
 }
 
 template <int TM>
 void launch_tm(const IgemmCfg& c, int fast, dim3 grid, hipStream_t st, const float* src, const float* apack,
                const int2* table, const float* bias, float* dst, float* psum, float* psq, float* slab,
                const IgemmParams& p) {
-  if (c.bn == 256) launch_one<TM, 256, 1, true>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else if (fast == 1) launch_one<TM, 128, 1, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else if (fast == 2) launch_one<TM, 128, 2, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else launch_one<TM, 128, 0, false>(grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  if (c.bn == 256) launch_one<TM, 256, 1, true>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else if (fast == 1) launch_one<TM, 128, 1, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else if (fast == 2) launch_one<TM, 128, 2, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  else launch_one<TM, 128, 0, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
 }
 
 inline int stat_parts(const IgemmCfg& c, long long Ntot) {
@@ -777,15 +889,18 @@ int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack,
       const long long nA = (long long)p.tilesM * p.tilesN, nB = (long long)tmB * tnB;
       if (nA + nB > 0x7fffffffLL) return GCA_EINVAL;
       bool done = true;
+#define GCA_2PL(A, B, F, M)                                                                                                  \
+  hipLaunchKernelGGL((conv_igemm_2phase_kernel<A, B, F, M>), dim3((unsigned)(nA + nB)), dim3(256), 0, st, src, apack, table,  \
+                     bias, dst, ps, pq, p, (int)nA, tmB, tnB)
 #define GCA_2P(A, B)                                                                                                          \
   if (c.bm == 32 * A && c.tail_bm == 32 * B) {                                                                                \
-    if (fast == 1) hipLaunchKernelGGL((conv_igemm_2phase_kernel<A, B, 1>), dim3((unsigned)(nA + nB)), dim3(256), 0, st, src,  \
-                                      apack, table, bias, dst, ps, pq, p, (int)nA, tmB, tnB);                                \
-    else hipLaunchKernelGGL((conv_igemm_2phase_kernel<A, B, 2>), dim3((unsigned)(nA + nB)), dim3(256), 0, st, src, apack,     \
-                            table, bias, dst, ps, pq, p, (int)nA, tmB, tnB);                                                 \
+    if (c.math == 1) { if (fast == 1) GCA_2PL(A, B, 1, 1); else GCA_2PL(A, B, 2, 1); }                                        \
+    else if (c.math == 2) { if (fast == 1) GCA_2PL(A, B, 1, 2); else GCA_2PL(A, B, 2, 2); }                                   \
+    else { if (fast == 1) GCA_2PL(A, B, 1, 0); else GCA_2PL(A, B, 2, 0); }                                                    \
   } else
       GCA_2P(2, 1) GCA_2P(3, 1) GCA_2P(3, 2) GCA_2P(4, 1) GCA_2P(4, 2) GCA_2P(5, 1) GCA_2P(5, 2) { done = false; }
 #undef GCA_2P
+#undef GCA_2PL
       if (done) return gca_launch_status();
     }
     p.tilesM = (int)gca_ceil_div(p.DK, c.bm); p.tilesN = c.main_cols; p.tileN_off = 0;
@@ -825,11 +940,30 @@ int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
   return need;
 }
 
+int g_conv_math = -1;       // -1: not read yet (GCA_CONV_MATH)
+
 }  // namespace
+
+namespace gca_conv {
+int conv_math() {
+  if (g_conv_math < 0) {
+    const char* e = getenv("GCA_CONV_MATH");
+    g_conv_math = !e ? 0 : (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : (!strcmp(e, "bf16x6") || !strcmp(e, "2")) ? 2 : 0;
+  }
+  return g_conv_math;
+}
+}  // namespace gca_conv
 
 extern "C" {
 
-int gca_version(void) { return 6; }
+int gca_version(void) { return 7; }
+
+int gca_set_conv_math(int mode) {
+  if (mode < 0 || mode > 2) return GCA_EINVAL;
+  g_conv_math = mode;
+  return GCA_OK;
+}
+int gca_get_conv_math(void) { return conv_math(); }
 
 int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   if (!geom_ok(g) || (which != 0 && which != 1)) return GCA_EINVAL;

@@ -58,7 +58,7 @@ __device__ __forceinline__ MaskT tap_valid_mask(const WgradParams& p, int id0, i
 // BVEC (pointwise-in-space convs: kh = kw = 1, unit spatial stride, no spatial padding): a table row's 4
 // consecutive positions are 4 consecutive floats of X, so the gather uses float4 loads too (and shares the
 // position arithmetic with the dY loads).
-template <int WM, int WN, int TM, int TN, bool AVEC, int FAST, bool BVEC>
+template <int WM, int WN, int TM, int TN, bool AVEC, int FAST, bool BVEC, int MATH>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dy, const int2* __restrict__ table,
     float* __restrict__ slab, WgradParams p) {
@@ -69,8 +69,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   constexpr int B_PER = BVEC ? BNW / 32 : BNW / 8;   // float4 or scalar gathers per thread for X
   static_assert(!BVEC || (AVEC && FAST == 1), "BVEC needs the float4 position mapping and the 32-bit tap mask");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDW];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BNW][LDW];
+  // row pitch: 32 k = 128 B as fp32 or bf16 hi+lo, 192 B as bf16 hi+mid+lo; +16 B pad (36 r and 52 r mod 64 both walk all
+  // 16 four-bank groups over 16 rows: conflict-free b128 fragment reads)
+  constexpr int LDP = MATH == 2 ? 52 : LDW, NP = math_parts(MATH);
+  __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BNW][LDP];
   __shared__ int2 Ts[BNW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     }
     breg[BVEC ? 0 : j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)((nx_bbase + (unsigned)e.x) | inv), 0, 0));
   };
-  constexpr int G = (WBK / 8) * TM * TN;                         // MFMA groups (4 dependent MFMAs each) per tile
+  constexpr int G = (MATH ? WBK / 16 : WBK / 8) * TM * TN;       // MFMA groups (4 exact / 3 bf16x3 MFMAs each) per tile
   constexpr int GSPAN = G > 2 ? G - 2 : 1;
   constexpr int GCHUNK = (B_PER + GSPAN - 1) / GSPAN;
   auto issue_piece = [&](int gi, int kt) __attribute__((always_inline)) {
@@ -207,7 +210,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
     for (int j = 0; j < B_PER; ++j) issue_b(j);
   };
+  // MATH >= 1 (bf16x3 / bf16x6, see conv3d.hip): a row of 32 k is four 8-k groups [hi x8 | (mid x8 |) lo x8]; the 16-byte
+  // operands of MFMA step t for a lane of half h sit at float index 4*NP*(2t + h) + {0, 4, (8)}.
+  auto store_split4 = [&](float* row, int chunk, float4 v) __attribute__((always_inline)) {     // k = 4*chunk .. +3
+    float* d = row + (chunk >> 1) * (4 * NP) + (chunk & 1) * 2;
+    if (MATH == 2) {
+      uint2 h, m, l;
+      split_bf16x3(v.x, v.y, h.x, m.x, l.x);
+      split_bf16x3(v.z, v.w, h.y, m.y, l.y);
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + 4) = m;
+      *reinterpret_cast<uint2*>(d + 8) = l;
+    } else {
+      uint2 h, l;
+      split_bf16x2(v.x, v.y, h.x, l.x);
+      split_bf16x2(v.z, v.w, h.y, l.y);
+      *reinterpret_cast<uint2*>(d) = h;
+      *reinterpret_cast<uint2*>(d + 4) = l;
+    }
+  };
+  auto store_split1 = [&](float* row, int k, float v) __attribute__((always_inline)) {
+    unsigned short* d = reinterpret_cast<unsigned short*>(row) + (k >> 3) * (8 * NP) + (k & 7);
+    if (MATH == 2) {
+      unsigned h, m, l;
+      split_bf16x3(v, 0.f, h, m, l);
+      d[0] = (unsigned short)h; d[8] = (unsigned short)m; d[16] = (unsigned short)l;
+    } else {
+      unsigned h, l;
+      split_bf16x2(v, 0.f, h, l);
+      d[0] = (unsigned short)h; d[8] = (unsigned short)l;
+    }
+  };
   auto store_tiles = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (MATH >= 1) {
+      if (AVEC) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) store_split4(&As[buf][ga + 32 * i][0], kq, avec[AVEC ? i : 0]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) store_split1(&As[buf][g + 8 * i][0], kl, areg[AVEC ? 0 : i]);
+      }
+      if (BVEC) {
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) store_split4(&Bs[buf][ga + 32 * j][0], kq, bvec[BVEC ? j : 0]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) store_split1(&Bs[buf][g + 8 * j][0], kl, breg[BVEC ? 0 : j]);
+      }
+      return;
+    }
     if (AVEC) {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) *reinterpret_cast<float4*>(&As[buf][ga + 32 * i][kq * 4]) = avec[i];
@@ -259,7 +310,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   };
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
-  if (TM * TN <= 2) {       // small tiles: unrolled by two with compile-time buffers, tail peeled (as in conv3d.hip)
+  if constexpr (MATH >= 1) {
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      const bool more = kt + 1 < kt1;
+#pragma unroll
+      for (int t = 0; t < WBK / 16; ++t) {
+        float4 af[TM][NP], bf[TN][NP];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            af[i][q] = *reinterpret_cast<const float4*>(&As[buf][wm * (TM * 32) + i * 32 + ll][4 * NP * (2 * t + lh) + 4 * q]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            bf[j][q] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][4 * NP * (2 * t + lh) + 4 * q]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
+            const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
+            if (MATH == 2) {
+              const bf16x8 xm = __builtin_bit_cast(bf16x8, af[i][1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      if (more) store_tiles(buf ^ 1);
+      __syncthreads();
+    }
+  } else if (TM * TN <= 2) {       // small tiles: unrolled by two with compile-time buffers, tail peeled (as in conv3d.hip)
     int kt = kt0;
     for (; kt + 2 < kt1; kt += 2) {
       tile(B0{}, std::true_type{}, kt + 1);
@@ -434,13 +528,21 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
           ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
 }
 
+template <int WM, int WN, int TM, int TN, int FAST, int MATH>
+void launch_wm(int avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
+               const WgradParams& p) {      // avec: 0 scalar, 1 float4 dY, 2 float4 dY and X
+  if (avec == 2 && FAST == 1)
+    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST == 1 ? 1 : 1, true, MATH>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  else if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST, false, MATH>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST, false, MATH>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+}
+
 template <int WM, int WN, int TM, int TN, int FAST>
 void launch_w(int avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
-              const WgradParams& p) {      // avec: 0 scalar, 1 float4 dY, 2 float4 dY and X
-  if (avec == 2 && FAST == 1)
-    hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST == 1 ? 1 : 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
-  else if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST, false>), grid, dim3(256), 0, st, x, dy, t, slab, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST, false>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+              const WgradParams& p) {
+  if (conv_math() == 1) launch_wm<WM, WN, TM, TN, FAST, 1>(avec, grid, st, x, dy, t, slab, p);
+  else if (conv_math() == 2) launch_wm<WM, WN, TM, TN, FAST, 2>(avec, grid, st, x, dy, t, slab, p);
+  else launch_wm<WM, WN, TM, TN, FAST, 0>(avec, grid, st, x, dy, t, slab, p);
 }
 
 template <int FAST>

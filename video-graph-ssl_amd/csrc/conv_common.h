@@ -5,7 +5,34 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 namespace gca_conv {
+
+// Conv arithmetic (include/gca_hip.h, gca_set_conv_math): 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = bf16x3, 2 = bf16x6:
+// fp32 operands split in the kernel into 2 / 3 bf16 parts, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+// Defined in conv3d.hip (gca_set_conv_math / GCA_CONV_MATH).
+int conv_math();
+constexpr int math_parts(int math) { return math == 2 ? 3 : 2; }   // bf16 parts per fp32 operand element
+
+// (x0, x1) -> packed bf16 pairs hi = bf16(x) and lo = bf16(x - hi)  (round to nearest even, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split_bf16x2(float x0, float x1, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+}
+// three parts: x = hi + mid + lo up to 2^-27 |x| (both residuals are exact in fp32)
+__device__ __forceinline__ void split_bf16x3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  const f32x2 v = {x0, x1};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+  const f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+  const f32x2 r2 = {r.x - __uint_as_float(mid << 16), r.y - __uint_as_float(mid & 0xffff0000u)};
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf16x2));
+}
 
 constexpr int BK = 16;          // GEMM-K tile of the forward/dgrad kernels
 constexpr int WBK = 32;         // GEMM-K (spatial) tile of the wgrad kernel

@@ -53,6 +53,20 @@ _TUNE_DIRTY = [False]
 _TUNE_PATH = os.environ.get('GCA_TUNE_CACHE', '')
 
 
+CONV_MATH = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}
+
+
+def set_conv_math(mode):
+    """Arithmetic of the conv kernels: 'f32' (fp32 MFMA), 'bf16x6' (fp32-grade split products) or 'bf16x3' (faster); see
+    gca_set_conv_math in include/gca_hip.h.  Plans tuned under one mode re-tune under the other (cache keys differ),
+    but a plan object keeps the configuration it was tuned with: set the mode before building the model."""
+    H.call('gca_set_conv_math', CONV_MATH[mode])
+
+
+def get_conv_math():
+    return ('f32', 'bf16x3', 'bf16x6')[H.lib.gca_get_conv_math()]
+
+
 def load_tune_cache(path):
     import json
     with open(path) as f:
@@ -184,7 +198,7 @@ class ConvPlan:
         N, K, OD, OH, OW = self.out_shape
         key = '%d:%s' % (which, ','.join(str(int(v)) for v in (g.N, g.C, g.D, g.H, g.W, g.K, g.kd, g.kh, g.kw, g.sd, g.sh,
                                                                  g.sw, g.pd, g.ph, g.pw, g.x_batch_stride)))
-        key = 'v%d:%s' % (H.lib.gca_version(), key)
+        key = 'v%d%s:%s' % (H.lib.gca_version(), ('', 'b', 'c')[H.lib.gca_get_conv_math()], key)
         hit = _TUNE_CACHE.get(key)
         if hit is not None:
             if which == 0:
@@ -268,13 +282,15 @@ class ConvPlan:
 
 
 @functools.lru_cache(maxsize=None)
-def _conv_plan(N, Cin, D, Hh, W, K, k, s, p, dev_type, dev_index, xbs):
+def _conv_plan(N, Cin, D, Hh, W, K, k, s, p, dev_type, dev_index, xbs, math):
     return ConvPlan(N, Cin, D, Hh, W, K, k, s, p, torch.device(dev_type, dev_index), xbs)
 
 
 def conv_plan(x_shape, K, k, s, p, device, x_batch_stride=0):
     N, Cin, D, Hh, W = x_shape
-    return _conv_plan(N, Cin, D, Hh, W, K, _t3(k), _t3(s), _t3(p), device.type, device.index, int(x_batch_stride))
+    # one plan (= one set of tuned launch configurations) per geometry AND arithmetic mode
+    return _conv_plan(N, Cin, D, Hh, W, K, _t3(k), _t3(s), _t3(p), device.type, device.index, int(x_batch_stride),
+                      H.lib.gca_get_conv_math())
 
 
 def conv_pack(plan, which, w, out=None):
