@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--backbone', default='R2P1D18')
     ap.add_argument('--queue', type=int, default=0, help='0 = 4096 at N=1, 65536 at N>1 (BASELINE configs 2/3)')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', default='bf16x3', choices=['bf16x3', 'bf16x6', 'f32'],
+    ap.add_argument('--math', default='bf16x6', choices=['bf16x3', 'bf16x6', 'f32'],
                     help="conv arithmetic (include/gca_hip.h gca_set_conv_math): bf16x3 = fp32 operands split into bf16 "
                          "hi+lo, three bf16 MFMAs per product, fp32 accumulate (4.5e-6 rel. error vs fp32 MFMA, measured); "
                          "bf16x6 = hi+mid+lo, six products, fp32-grade; f32 = fp32 MFMA.  The other modes are timed too and "

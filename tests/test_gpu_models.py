@@ -14,9 +14,10 @@ DEV = torch.device('cuda:0')
 @pytest.fixture(params=['f32', 'bf16x6', 'bf16x3'])
 def conv_math(request, pkg):
     """Both arithmetic modes of the conv kernels (include/gca_hip.h gca_set_conv_math) are held to north_star's 1e-3."""
+    default = pkg.engine.ops.get_conv_math()
     pkg.engine.ops.set_conv_math(request.param)
     yield request.param
-    pkg.engine.ops.set_conv_math('f32')
+    pkg.engine.ops.set_conv_math(default)
 
 
 def _engine(pkg):
