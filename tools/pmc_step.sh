@@ -5,11 +5,12 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_step
 mkdir -p $O
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-other-math ${GCA_BENCH_MATH:+--math $GCA_BENCH_MATH}"
 export GCA_TUNE_CACHE=$O/tune_cache.json      # pass 1 measures the launch configurations, passes 2-3 reuse them
 rm -f $GCA_TUNE_CACHE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py $ARGS > $O/trace.json 2> $O/trace.err || exit 1
 echo trace done
+[ -n "$GCA_TRACE_ONLY" ] && exit 0
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -o f -- python3 $R/bench.py $ARGS > $O/fetch.json 2> $O/fetch.err || exit 2
 echo fetch done
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -o w -- python3 $R/bench.py $ARGS > $O/write.json 2> $O/write.err || exit 3

@@ -347,45 +347,163 @@ __device__ __forceinline__ void igemm_tile(
   using B1 = std::integral_constant<int, 1>;
   if constexpr (MATH >= 1) {
     // bf16x3: x*y ~= xh*yh + xh*yl + xl*yh (the dropped xl*yl term and the rounding of the lo parts are ~2^-17 relative).
-    // bf16x6: x*y ~= hh + hm + mh + hl + lh + mm (dropped terms and part rounding <= 2^-25: fp32-grade products).
+    // bf16x6: x*y ~= hh + hm + mh + hl + lh + mm (dropped terms and part rounding <= 2^-25).
     // fp32 accumulation in both.  One k-tile = TM*TN groups of 3 / 6 32-cycle MFMAs -- 5.3x / 2.7x less matrix-pipe time
-    // than the fp32 MFMA path's 8 x 64 cycles, so the loop is paced by the gathers and the LDS instead.
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
-      const bool more = kt + 1 < kt1;
-      float4 af[TM][NP], bf[TN][NP];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const float4*>(&As[buf][i * 32 + ll][4 * NP * lh + 4 * q]);
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) bf[j][q] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][4 * NP * lh + 4 * q]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
-          const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
-          if (MATH == 2) {
-            const bf16x8 xm = __builtin_bit_cast(bf16x8, af[i][1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) issue_piece(i * TN + j, kt + 1);
-          __builtin_amdgcn_sched_barrier(0);
+    // than the fp32 MFMA path's 8 x 64 cycles, i.e. SHORTER than a trip to L2/HBM.  The fetch therefore runs TWO tiles
+    // ahead: while tile kt is multiplied out of LDS, tile kt+1 is in flight in one register set and the loads of tile
+    // kt+2 are issued into the other (the loop is unrolled by two so that both sets are plain registers).
+    if constexpr (!VEC && TM <= 3) {
+      struct Fetch { float4 a0, a1, a2; float b[VEC ? 1 : B_PER]; float4 bv[VEC ? B_PER : 1]; int2 e[B_PER]; };
+      Fetch F0, F1;
+      auto f_table = [&](Fetch& F, int kt) __attribute__((always_inline)) {
+        const int2* trow = table + kt * BK + __builtin_amdgcn_readfirstlane(r0);
+  #pragma unroll
+        for (int i = 0; i < B_PER; ++i) F.e[i] = trow[i];
+      };
+      auto f_a = [&](Fetch& F, int kt) __attribute__((always_inline)) {
+        F.a0 = *reinterpret_cast<const float4*>(arow + ao0 + kt * BK);
+        if (A_F4 > 1) F.a1 = *reinterpret_cast<const float4*>(arow + ao1 + kt * BK);
+        if (A_F4 > 2) F.a2 = *reinterpret_cast<const float4*>(arow + ao2 + kt * BK);
+      };
+      auto f_gather = [&](Fetch& F, int i) __attribute__((always_inline)) {
+        int inv;
+        if (FAST == 1) {
+          inv = __builtin_amdgcn_sbfe((int)ilo, F.e[i].y, 1);
+        } else if (FAST == 2) {
+          const unsigned hsel = (unsigned)-((F.e[i].y >> 5) & 1);
+          inv = __builtin_amdgcn_sbfe((int)(ilo ^ ((ilo ^ ihi) & hsel)), F.e[i].y, 1);
+        } else {
+          int off, dd, dh, dw, rvalid;
+          decode_row(F.e[i], off, dd, dh, dw, rvalid);
+          bool k = cvalid & (rvalid != 0);
+          if (chkD) k = k & ((unsigned)(id0 + dd) < (unsigned)p.SD);
+          if (chkH) k = k & ((unsigned)(ih0 + dh) < (unsigned)p.SH);
+          if (chkW) k = k & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
+          inv = k ? 0 : -1;
         }
-      if (more) store_tiles(buf ^ 1);
-      __syncthreads();
+        const unsigned voff = (cb4 + (unsigned)F.e[i].x) | (unsigned)inv;
+        if (VEC) {
+          const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+          F.bv[VEC ? i : 0] = make_float4(f.x, f.y, f.z, f.w);
+        } else {
+          F.b[VEC ? 0 : i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+        }
+      };
+      auto f_all = [&](Fetch& F, int kt) __attribute__((always_inline)) {
+        f_table(F, kt); f_a(F, kt);
+  #pragma unroll
+        for (int i = 0; i < B_PER; ++i) f_gather(F, i);
+      };
+      auto f_piece = [&](Fetch& F, int g, int kt) __attribute__((always_inline)) {
+        if (G == 1) f_all(F, kt);
+        else if (g == 0) { f_table(F, kt); f_a(F, kt); }
+        else if (g <= GSPAN) {
+  #pragma unroll
+          for (int i = 0; i < B_PER; ++i)
+            if (i >= (g - 1) * GCHUNK && i < g * GCHUNK) f_gather(F, i);
+        }
+      };
+      auto stash = [&](Fetch& F, int buf) __attribute__((always_inline)) {      // convert + write to LDS (store_tiles reads a0.. / breg / bvec)
+        a0 = F.a0; a1 = F.a1; a2 = F.a2;
+  #pragma unroll
+        for (int i = 0; i < (VEC ? 1 : B_PER); ++i) breg[i] = F.b[i];
+  #pragma unroll
+        for (int i = 0; i < (VEC ? B_PER : 1); ++i) bvec[i] = F.bv[i];
+        store_tiles(buf);
+      };
+      // tile kt is in LDS[buf]; Fin holds tile kt+1 (in flight); tile kt+2 is fetched into Fnew.  No branch depends on
+      // "is there a next tile": past the end the last tile is fetched / stored again (clamped index, nobody reads it), so
+      // that the compiler can wait with exact vmcnt counts (a conditional fetch forces s_waitcnt vmcnt(0) at every use).
+      auto body = [&](auto BUF, Fetch& Fin, Fetch& Fnew, int kt) __attribute__((always_inline)) {
+        constexpr int buf = decltype(BUF)::value;
+        const int ktn = min(kt + 2, kt1 - 1);
+        float4 bf[TN][NP], afc[NP], afn[NP];
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
+          for (int q = 0; q < NP; ++q) bf[j][q] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][4 * NP * lh + 4 * q]);
+  #pragma unroll
+        for (int q = 0; q < NP; ++q) afc[q] = *reinterpret_cast<const float4*>(&As[buf][ll][4 * NP * lh + 4 * q]);
+  #pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if (i + 1 < TM) {         // next row tile's fragments, one group ahead of their MFMAs
+  #pragma unroll
+            for (int q = 0; q < NP; ++q) afn[q] = *reinterpret_cast<const float4*>(&As[buf][(i + 1) * 32 + ll][4 * NP * lh + 4 * q]);
+          }
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, afc[0]), xl = __builtin_bit_cast(bf16x8, afc[NP - 1]);
+            const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
+            if (MATH == 2) {
+              const bf16x8 xm = __builtin_bit_cast(bf16x8, afc[1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f_piece(Fnew, i * TN + j, ktn);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+  #pragma unroll
+          for (int q = 0; q < NP; ++q) afc[q] = afn[q];
+        }
+        stash(Fin, buf ^ 1);
+        __syncthreads();
+      };
+      if (kt0 < kt1) {
+        f_all(F1, min(kt0 + 1, kt1 - 1));
+        for (int kt = kt0; kt < kt1; kt += 2) {
+          body(B0{}, F1, F0, kt);
+          if (kt + 1 >= kt1) break;
+          body(B1{}, F0, F1, kt + 1);
+        }
+      }
+    } else {
+      // tall / 256-column tiles: two register sets cost them a resident workgroup (measured slower), and their MFMA
+      // phase is long enough for a one-tile-ahead fetch
+      for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        float4 af[TM][NP], bf[TN][NP];
+  #pragma unroll
+        for (int i = 0; i < TM; ++i)
+  #pragma unroll
+          for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const float4*>(&As[buf][i * 32 + ll][4 * NP * lh + 4 * q]);
+  #pragma unroll
+        for (int j = 0; j < TN; ++j)
+  #pragma unroll
+          for (int q = 0; q < NP; ++q) bf[j][q] = *reinterpret_cast<const float4*>(&Bs[buf][wn * (TN * 32) + j * 32 + ll][4 * NP * lh + 4 * q]);
+  #pragma unroll
+        for (int i = 0; i < TM; ++i)
+  #pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
+            const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
+            if (MATH == 2) {
+              const bf16x8 xm = __builtin_bit_cast(bf16x8, af[i][1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
+            } else {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) issue_piece(i * TN + j, kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        if (more) store_tiles(buf ^ 1);
+        __syncthreads();
+      }
     }
   } else if (TM <= 2 && !VEC) {
     // small tiles: the loop is unrolled by two (buffers 0 / 1) and the tail peeled -- the per-tile scalar
