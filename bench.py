@@ -114,7 +114,7 @@ def conv_layers_of(model, x_shape, pkg):
 def _sym(c):
     """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10}."""
     vec, fast = c[1] == 256, (c[3] >> 8) & 3       # bit 10 only says the class COULD use float4 gathers
-    return 'conv_igemm_kernel<%d,%d,%d,%s,%d>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false', _MATH[0])
+    return 'conv_igemm_kernel<%d,%d,%d,%s,%d>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false', (c[3] >> 12) & 3)
 
 
 _MATH = [0]          # conv arithmetic of the kernels being timed: 0 fp32 MFMA, 1 bf16x3, 2 bf16x6 (set in main from --math)

@@ -71,6 +71,10 @@ typedef struct {
   int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile shape index 1..10 (see gca_conv_wgrad_cfg), 0 = heuristic */
   int32_t tune_fwd_tail, tune_dgrad_tail;      /* two-phase launch: (short tile rows / 32) | (column tiles run with the tall
                                                   tile << 8); 0 = single launch.  Used only with 128-column tiles, split 1 */
+  int32_t tune_fwd_math, tune_dgrad_math, tune_wgrad_math;  /* 0 = the arithmetic set by gca_set_conv_math; 1 + m = run this
+                                                  pass with arithmetic m, honoured only when m is at least as accurate as
+                                                  the mode in force (f32 > bf16x6 > bf16x3): the mode is a floor on
+                                                  accuracy and the host pins whichever admissible kernel is fastest */
 } gca_conv_geom;
 
 /* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward
@@ -103,7 +107,8 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_
  * layout [K][P], P = gca_conv_fwd_stat_parts(g). */
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
 /* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad), first non-empty class:
- * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask kind (0 none, 1: <=31 taps, 2: <=62)<<8 | float4-gather<<10}. */
+ * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask kind (0 none, 1: <=31 taps, 2: <=62)<<8 | float4-gather<<10 |
+ *         arithmetic (0 f32, 1 bf16x3, 2 bf16x6)<<12}. */
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
 /* Layers whose output grid cannot fill the 256 CUs split the reduction over workgroups; the fp32
  * partial slabs live in `ws` (gca_conv_fwd_ws_bytes / gca_conv_dgrad_ws_bytes; 0 = not needed, ws may
@@ -123,7 +128,7 @@ int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g);
 int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream);
 /* Launch shape the wgrad kernel will use for g: out4 = {tile rows (output channels), tile columns (C*taps),
- * split-K factor, shape index | float4 dY loads<<8 | tap-mask kind<<9}. */
+ * split-K factor, shape index | float4 dY loads<<8 | tap-mask kind<<9 | float4 X gathers<<11 | arithmetic<<12}. */
 int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4);
 
 /* db[k] (+)= sum over (n, spatial) of dy[n,k,:]   (bias gradient of the nn.Linear layers) */

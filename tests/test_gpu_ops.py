@@ -169,6 +169,45 @@ def test_conv_wgrad_tap_mask_kinds(ops, ctol, shape, K, k, s, p):
         assert rel_err(dw, wr.grad) < ctol, (idx, plan.cfg(2))
 
 
+def test_conv_math_mode_is_a_floor_on_accuracy(ops):
+    """tune_*_math = 1 + arithmetic overrides a pass only towards MORE accurate kernels (f32 > bf16x6 > bf16x3): in bf16x3
+    mode a pass pinned to the fp32 MFMA kernel is fp32-accurate; in f32 mode a bf16x3 pin is ignored."""
+    torch.manual_seed(1)
+    shape, K, k, s, p = (2, 48, 4, 10, 10), 80, (3, 3, 3), (1, 1, 1), (1, 1, 1)
+    x, w = torch.randn(shape, device=DEV), torch.randn((K, shape[1]) + k, device=DEV) * 0.05
+    default = ops.get_conv_math()
+    try:
+        ops.set_conv_math('f32')
+        plan = ops.ConvPlan(*shape, K, k, s, p, DEV)
+        plan.tuned = [True, True, True]
+        wp = ops.conv_pack(plan, 0, w)
+        y_f32 = ops.conv_fwd(plan, x, wp).clone()
+        dy = torch.randn_like(y_f32)
+        dw_f32 = torch.zeros_like(w); ops.conv_wgrad(plan, x, dy, dw_f32, accumulate=True)
+        plan.g.tune_fwd_math = plan.g.tune_wgrad_math = 2          # bf16x3 asked for, f32 in force: ignored
+        plan.refresh()
+        assert (plan.cfg(0)[3] >> 12) & 3 == 0 and (plan.cfg(2)[3] >> 12) & 3 == 0
+        assert torch.equal(ops.conv_fwd(plan, x, wp), y_f32)
+        ops.set_conv_math('bf16x3')
+        plan.g.tune_fwd_math = plan.g.tune_wgrad_math = 0
+        plan.refresh()
+        assert (plan.cfg(0)[3] >> 12) & 3 == 1 and (plan.cfg(2)[3] >> 12) & 3 == 1
+        e3 = rel_err(ops.conv_fwd(plan, x, wp), y_f32)
+        assert 1e-7 < e3 < 5e-5
+        plan.g.tune_fwd_math = plan.g.tune_wgrad_math = 1          # fp32 MFMA pinned inside bf16x3 mode
+        plan.refresh()
+        assert (plan.cfg(0)[3] >> 12) & 3 == 0 and (plan.cfg(2)[3] >> 12) & 3 == 0
+        assert torch.equal(ops.conv_fwd(plan, x, wp), y_f32)
+        dw = torch.zeros_like(w); ops.conv_wgrad(plan, x, dy, dw, accumulate=True)
+        assert torch.equal(dw, dw_f32)
+        plan.g.tune_fwd_math = 3                                    # bf16x6 inside bf16x3 mode
+        plan.refresh()
+        assert (plan.cfg(0)[3] >> 12) & 3 == 2
+        assert rel_err(ops.conv_fwd(plan, x, wp), y_f32) < e3
+    finally:
+        ops.set_conv_math(default)
+
+
 def test_conv_batch_stride_views(ops):
     """The two views of a (b,6,T,H,W) batch are read in place (tools/...dis.py:404)."""
     torch.manual_seed(1)

@@ -30,7 +30,8 @@ class ConvGeom(C.Structure):
     _fields_ = [(n, c_i32) for n in ('N', 'C', 'D', 'H', 'W', 'K', 'kd', 'kh', 'kw', 'sd', 'sh', 'sw',
                                      'pd', 'ph', 'pw', 'OD', 'OH', 'OW')] + [('x_batch_stride', c_i64)] + \
                [(n, c_i32) for n in ('tune_fwd_bm', 'tune_fwd_splits', 'tune_dgrad_bm', 'tune_dgrad_splits',
-                                     'tune_wgrad_splits', 'tune_wgrad_tile', 'tune_fwd_tail', 'tune_dgrad_tail')]
+                                     'tune_wgrad_splits', 'tune_wgrad_tile', 'tune_fwd_tail', 'tune_dgrad_tail',
+                                     'tune_fwd_math', 'tune_dgrad_math', 'tune_wgrad_math')]
 
 
 class PoolGeom(C.Structure):

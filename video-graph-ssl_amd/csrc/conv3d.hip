@@ -938,7 +938,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
   int fbm, fs, tail;
   tune_of(g, which, fbm, fs, tail);
   IgemmCfg cf = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
-  cf.math = conv_math();
+  cf.math = resolve_math(which == 0 ? g->tune_fwd_math : g->tune_dgrad_math);
   // Two-phase launch (measured configurations only; single-class passes, 128-column tiles, no split-K): the first
   // `main_cols` column tiles run with the tall tile, the rest with a short one -- the last, partly filled wave of tall
   // workgroups (up to a quarter of the launch time on the layer-1 shapes) becomes a full wave of short ones.
@@ -1074,7 +1074,7 @@ int conv_math() {
 
 extern "C" {
 
-int gca_version(void) { return 7; }
+int gca_version(void) { return 8; }
 
 int gca_set_conv_math(int mode) {
   if (mode < 0 || mode > 2) return GCA_EINVAL;
@@ -1232,7 +1232,7 @@ int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
     IgemmParams p{};
     class_params(g, which, c, p);
     const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10);
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12);
     return GCA_OK;
   }
   return GCA_EINVAL;

@@ -29,6 +29,7 @@ struct WgradParams {
   int tilesM, tilesN, splits;
   int kt_per_split, kt_total;
   int chk;
+  int math;                 // arithmetic of this launch (host side only)
   unsigned Ktot;            // NB*OD*OH*OW (GEMM K) -- < 2^30
   unsigned x_nstride;       // elements between clips of x
   unsigned x_bytes, dy_bytes, slab_bytes;
@@ -523,6 +524,7 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   if (g->tune_wgrad_splits > 0) want = g->tune_wgrad_splits < p.kt_total ? g->tune_wgrad_splits : p.kt_total;
   p.kt_per_split = (int)gca_ceil_div(p.kt_total, want);
   p.splits = (int)gca_ceil_div(p.kt_total, p.kt_per_split);
+  p.math = resolve_math(g->tune_wgrad_math);
   p.chk = ((g->pd > 0 || (g->OD - 1) * g->sd + g->kd > g->D) ? 1 : 0) |
           ((g->ph > 0 || (g->OH - 1) * g->sh + g->kh > g->H) ? 2 : 0) |
           ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
@@ -540,8 +542,8 @@ void launch_wm(int avec, dim3 grid, hipStream_t st, const float* x, const float*
 template <int WM, int WN, int TM, int TN, int FAST>
 void launch_w(int avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
               const WgradParams& p) {
-  if (conv_math() == 1) launch_wm<WM, WN, TM, TN, FAST, 1>(avec, grid, st, x, dy, t, slab, p);
-  else if (conv_math() == 2) launch_wm<WM, WN, TM, TN, FAST, 2>(avec, grid, st, x, dy, t, slab, p);
+  if (p.math == 1) launch_wm<WM, WN, TM, TN, FAST, 1>(avec, grid, st, x, dy, t, slab, p);
+  else if (p.math == 2) launch_wm<WM, WN, TM, TN, FAST, 2>(avec, grid, st, x, dy, t, slab, p);
   else launch_wm<WM, WN, TM, TN, FAST, 0>(avec, grid, st, x, dy, t, slab, p);
 }
 
@@ -580,7 +582,7 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
   WgradPlan pl{};
   wgrad_plan(g, pl);
   out4[0] = WGRAD_SHAPES[pl.shape].bm; out4[1] = WGRAD_SHAPES[pl.shape].bn; out4[2] = pl.p.splits;
-  out4[3] = pl.shape | (pl.avec << 8) | (pl.fast << 9) | (pl.bvec << 11);
+  out4[3] = pl.shape | (pl.avec << 8) | (pl.fast << 9) | (pl.bvec << 11) | (pl.p.math << 12);
   return GCA_OK;
 }
 

@@ -16,6 +16,13 @@ namespace gca_conv {
 // Defined in conv3d.hip (gca_set_conv_math / GCA_CONV_MATH).
 int conv_math();
 constexpr int math_parts(int math) { return math == 2 ? 3 : 2; }   // bf16 parts per fp32 operand element
+// arithmetic of one pass: the tune_*_math override (1 + m) when m is at least as accurate as the mode in force
+inline int math_rank(int m) { return m == 0 ? 2 : m == 2 ? 1 : 0; }     // f32 > bf16x6 > bf16x3
+inline int resolve_math(int tune_math) {
+  const int mode = conv_math();
+  if (tune_math >= 1 && tune_math <= 3 && math_rank(tune_math - 1) >= math_rank(mode)) return tune_math - 1;
+  return mode;
+}
 
 // (x0, x1) -> packed bf16 pairs hi = bf16(x) and lo = bf16(x - hi)  (round to nearest even, v_cvt_pk_bf16_f32)
 __device__ __forceinline__ void split_bf16x2(float x0, float x1, unsigned& hi, unsigned& lo) {
@@ -87,6 +94,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && (v >> 10) <= 1)) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
   if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 10) return false;
+  for (int v : {g->tune_fwd_math, g->tune_dgrad_math, g->tune_wgrad_math}) if (v < 0 || v > 3) return false;
   for (int v : {g->tune_fwd_tail, g->tune_dgrad_tail}) if (v < 0 || (v != 0 && ((v & 255) < 1 || (v & 255) > 4))) return false;
   return true;
 }

@@ -200,36 +200,36 @@ class ConvPlan:
                                                                  g.sw, g.pd, g.ph, g.pw, g.x_batch_stride)))
         key = 'v%d%s:%s' % (H.lib.gca_version(), ('', 'b', 'c')[H.lib.gca_get_conv_math()], key)
         hit = _TUNE_CACHE.get(key)
-        if hit is not None:
+
+        def apply(c):
+            # igemm: (tile code, splits, tail code, math code); wgrad: (tile shape, splits, math code); short = zeros
             if which == 0:
-                g.tune_fwd_bm, g.tune_fwd_splits = hit[0], hit[1]
-                g.tune_fwd_tail = hit[2] if len(hit) > 2 else 0
+                g.tune_fwd_bm, g.tune_fwd_splits = c[0], c[1]
+                g.tune_fwd_tail = c[2] if len(c) > 2 else 0
+                g.tune_fwd_math = c[3] if len(c) > 3 else 0
             elif which == 1:
-                g.tune_dgrad_bm, g.tune_dgrad_splits = hit[0], hit[1]
-                g.tune_dgrad_tail = hit[2] if len(hit) > 2 else 0
+                g.tune_dgrad_bm, g.tune_dgrad_splits = c[0], c[1]
+                g.tune_dgrad_tail = c[2] if len(c) > 2 else 0
+                g.tune_dgrad_math = c[3] if len(c) > 3 else 0
             else:
-                g.tune_wgrad_tile, g.tune_wgrad_splits = hit
+                g.tune_wgrad_tile, g.tune_wgrad_splits = c[0], c[1]
+                g.tune_wgrad_math = c[2] if len(c) > 2 else 0
+            self.refresh()
+
+        if hit is not None:
+            apply(hit)
             if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0:      # still a valid launch code for this library
-                self.refresh()
                 return
-            g.tune_fwd_bm = g.tune_fwd_splits = g.tune_dgrad_bm = g.tune_dgrad_splits = 0
-            g.tune_wgrad_tile = g.tune_wgrad_splits = g.tune_fwd_tail = g.tune_dgrad_tail = 0
+            apply((0, 0, 0, 0) if which < 2 else (0, 0, 0))
         if which == 0:
             cands = self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)
         elif which == 1:
             cands = self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)
         else:
             cands = self._wgrad_candidates(K, g.C * self.taps, -(-(N * OD * OH * OW) // 32))
-        def apply(c):
-            if which == 0:
-                g.tune_fwd_bm, g.tune_fwd_splits = c[0], c[1]
-                g.tune_fwd_tail = c[2] if len(c) > 2 else 0
-            elif which == 1:
-                g.tune_dgrad_bm, g.tune_dgrad_splits = c[0], c[1]
-                g.tune_dgrad_tail = c[2] if len(c) > 2 else 0
-            else:
-                g.tune_wgrad_tile, g.tune_wgrad_splits = c
-            self.refresh()
+        # The arithmetic mode is a floor on accuracy: a pass may run a MORE accurate kernel when that one is faster
+        # (tune_*_math = 1 + arithmetic; f32 > bf16x6 > bf16x3).  0 = the mode itself.
+        maths = {0: (0,), 2: (0, 1), 1: (0, 3, 1)}[H.lib.gca_get_conv_math()]
 
         def measure(c):
             apply(c)
@@ -241,10 +241,12 @@ class ConvPlan:
                 return None
 
         timed = []
-        for c in cands:
-            t = measure(c)
-            if t is not None:
-                timed.append((t, tuple(c)))
+        for m in maths:
+            for c in cands:
+                c = (c[0], c[1], 0, m) if which < 2 else (c[0], c[1], m)
+                t = measure(c)
+                if t is not None:
+                    timed.append((t, c))
         timed.sort()
         if which < 2 and timed:
             # two-phase launches on the fastest single-launch shapes: tall tiles for the full waves of workgroups, short
@@ -253,7 +255,7 @@ class ConvPlan:
             single_class = which == 0 or (g.sd == 1 and g.sh == 1 and g.sw == 1)
             tilesN = -(-Ntot // 128)
             for _, base in list(timed[:2]):
-                bm, sp = base[0], base[1]
+                bm, sp, m = base[0], base[1], base[3]
                 if not single_class or sp != 1 or bm >= 1024 or bm <= 32:
                     continue
                 tilesM = -(-M // bm)
@@ -267,7 +269,7 @@ class ConvPlan:
                     for tail_rows in (32, 64):
                         if tail_rows >= bm:
                             continue
-                        c = (bm, 1, (tail_rows // 32) | (main_cols << 8))
+                        c = (bm, 1, (tail_rows // 32) | (main_cols << 8), m)
                         t = measure(c)
                         if t is not None:
                             timed.append((t, c))
@@ -278,7 +280,7 @@ class ConvPlan:
             _TUNE_DIRTY[0] = True
             apply(best)
         else:
-            apply((0, 0, 0) if which < 2 else (0, 0))
+            apply((0, 0, 0, 0) if which < 2 else (0, 0, 0))
 
 
 @functools.lru_cache(maxsize=None)
