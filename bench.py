@@ -111,10 +111,14 @@ def conv_layers_of(model, x_shape, pkg):
     return out
 
 
-def _sym(c):
-    """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10}."""
-    vec, fast = c[1] == 256, (c[3] >> 8) & 3       # bit 10 only says the class COULD use float4 gathers
-    return 'conv_igemm_kernel<%d,%d,%d,%s,%d>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false', (c[3] >> 12) & 3)
+def _sym(c, tail=0):
+    """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10 | arithmetic<<12} and
+    the plan's two-phase code (tune_*_tail: short-tile rows/32 | main column tiles<<8)."""
+    vec, fast, math = c[1] == 256, (c[3] >> 8) & 3, (c[3] >> 12) & 3       # bit 10 only says the class COULD use float4 gathers
+    tb = tail & 255
+    if tail and c[2] == 1 and c[1] == 128 and (c[3] & 255) == 1 and fast in (1, 2) and 0 < tb <= 2 and tb * 32 < c[0]:
+        return 'conv_igemm_2phase_kernel<%d,%d,%d,%d>' % (c[0] // 32, tb, fast, math)
+    return 'conv_igemm_kernel<%d,%d,%d,%s,%d>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false', math)
 
 
 _MATH = [0]          # conv arithmetic of the kernels being timed: 0 fp32 MFMA, 1 bf16x3, 2 bf16x6 (set in main from --math)
@@ -163,12 +167,12 @@ def kernel_timing(pkg, trainer, args):
         t_f, t_d = t, None
         c0 = plan.cfg(0)
         nbytes = 4.0 * (x.numel() + dy.numel() + w.numel())
-        add(_sym(c0), t, flops, 2, 1, nbytes)   # key + query forward
+        add(_sym(c0, plan.g.tune_fwd_tail), t, flops, 2, 1, nbytes)   # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
             # (the head's first Linear does: its input is the encoder feature)
             t = t_d = ev_time_ms(lambda: ops.conv_dgrad(plan, dy, wp1, dx, False), 5, 1)
             c1 = plan.cfg(1)
-            add(_sym(c1), t, flops, 1, max(1, c1[3] & 255), nbytes)
+            add(_sym(c1, plan.g.tune_dgrad_tail), t, flops, 1, max(1, c1[3] & 255), nbytes)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         cw = plan.cfg(2)
         add('conv_wgrad_kernel<%dx%d>' % (cw[0], cw[1]), t, flops, 1, 1, nbytes)
