@@ -73,8 +73,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   // row pitch: 32 k = 128 B as fp32 or bf16 hi+lo, 192 B as bf16 hi+mid+lo; +16 B pad (36 r and 52 r mod 64 both walk all
   // 16 four-bank groups over 16 rows: conflict-free b128 fragment reads)
   constexpr int LDP = MATH == 2 ? 52 : LDW, NP = math_parts(MATH);
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BNW][LDP];
+  // bf16x6 rows are 1.5x as long: ONE LDS buffer (the next tile waits in registers anyway; costs a second barrier per
+  // k-tile) keeps two workgroups per CU for every tile shape, so that one's split/store phase overlaps the other's MFMAs
+  constexpr int NBUF = MATH == 2 ? 1 : 2;
+  __shared__ __attribute__((aligned(16))) float As[NBUF][BM][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[NBUF][BNW][LDP];
   __shared__ int2 Ts[BNW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   using B1 = std::integral_constant<int, 1>;
   if constexpr (MATH >= 1) {
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
+      const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
       const bool more = kt + 1 < kt1;
 #pragma unroll
       for (int t = 0; t < WBK / 16; ++t) {
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             __builtin_amdgcn_sched_barrier(0);
           }
       }
-      if (more) store_tiles(buf ^ 1);
+      if (NBUF == 1) __syncthreads();                   // every wave is done reading the only buffer
+      if (more) store_tiles(NBUF == 2 ? buf ^ 1 : 0);
       __syncthreads();
     }
   } else if (TM * TN <= 2) {       // small tiles: unrolled by two with compile-time buffers, tail peeled (as in conv3d.hip)
