@@ -75,6 +75,11 @@ constexpr int LDK = BK + 4;     // LDS row pitch in floats (80 B)
 // pitch by arithmetic mode: a row of 16 k is 64 B as fp32 or as bf16 hi+lo pairs, 96 B as bf16 hi+mid+lo (+16 B pad each:
 // 20 r mod 64 and 28 r mod 64 both walk all 16 four-bank groups over 16 rows, so the b128 fragment reads are conflict-free)
 constexpr int lds_pitch(int math) { return math == 2 ? 28 : LDK; }
+// LDS buffers of the k-loop: the tall / 256-column bf16x6 tiles (96-byte rows) keep ONE (the next tile waits in registers
+// anyway; a second barrier per k-tile) so that 3-5 workgroups stay resident per CU instead of 2 and one workgroup's
+// split/store phase overlaps another's MFMAs
+constexpr int lds_bufs(int tm, bool vec, int math) { return (math == 2 && (vec || tm >= 4)) ? 1 : 2; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // The tile body is a device function so that ONE launch can mix two tile heights (conv_igemm_2phase_kernel below):
 // `bid` is the workgroup's logical id inside its phase, As_/Bs_/taptab the workgroup's LDS (sized by the caller).
@@ -468,7 +473,8 @@ __device__ __forceinline__ void igemm_tile(
       // tall / 256-column tiles: two register sets cost them a resident workgroup (measured slower), and their MFMA
       // phase is long enough for a one-tile-ahead fetch
       for (int kt = kt0; kt < kt1; ++kt) {
-        const int buf = (kt - kt0) & 1;
+        constexpr int NB = lds_bufs(TM, VEC, MATH);
+        const int buf = NB == 2 ? (kt - kt0) & 1 : 0;
         const bool more = kt + 1 < kt1;
         float4 af[TM][NP], bf[TN][NP];
   #pragma unroll
@@ -501,7 +507,8 @@ __device__ __forceinline__ void igemm_tile(
             if (more) issue_piece(i * TN + j, kt + 1);
             __builtin_amdgcn_sched_barrier(0);
           }
-        if (more) store_tiles(buf ^ 1);
+        if (NB == 1) __syncthreads();               // every wave is done reading the only buffer
+        if (more) store_tiles(NB == 2 ? buf ^ 1 : 0);
         __syncthreads();
       }
     }
@@ -647,8 +654,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
     const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, float* __restrict__ slab, IgemmParams p) {
-  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TM * lds_pitch(MATH)];
-  __shared__ __attribute__((aligned(16))) float Bs_[2 * BN * lds_pitch(MATH)];
+  __shared__ __attribute__((aligned(16))) float As_[lds_bufs(TM, VEC, MATH) * 32 * TM * lds_pitch(MATH)];
+  __shared__ __attribute__((aligned(16))) float Bs_[lds_bufs(TM, VEC, MATH) * BN * lds_pitch(MATH)];
   __shared__ int taptab[64];
   igemm_tile<TM, BN, FAST, VEC, MATH>(src, apack, table, bias, dst, psum, psq, slab, p, gca_xcd_remap(blockIdx.x, gridDim.x), As_, Bs_,
                                 taptab);
@@ -663,8 +670,8 @@ __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, IgemmParams p, int nA, int tilesM_B, int tilesN_B) {
   static_assert(TMB < TMA, "the tail uses the shorter tile");
-  __shared__ __attribute__((aligned(16))) float As_[2 * 32 * TMA * lds_pitch(MATH)];
-  __shared__ __attribute__((aligned(16))) float Bs_[2 * 128 * lds_pitch(MATH)];
+  __shared__ __attribute__((aligned(16))) float As_[cmax(lds_bufs(TMA, false, MATH) * TMA, lds_bufs(TMB, false, MATH) * TMB) * 32 * lds_pitch(MATH)];
+  __shared__ __attribute__((aligned(16))) float Bs_[cmax(lds_bufs(TMA, false, MATH), lds_bufs(TMB, false, MATH)) * 128 * lds_pitch(MATH)];
   __shared__ int taptab[64];
   if ((int)blockIdx.x < nA) {
     igemm_tile<TMA, 128, FAST, false, MATH>(src, apack, table, bias, dst, psum, psq, nullptr, p, gca_xcd_remap(blockIdx.x, nA), As_, Bs_, taptab);
