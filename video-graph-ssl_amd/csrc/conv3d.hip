@@ -78,7 +78,7 @@ constexpr int lds_pitch(int math) { return math == 2 ? 28 : LDK; }
 // LDS buffers of the k-loop: the tall / 256-column bf16x6 tiles (96-byte rows) keep ONE (the next tile waits in registers
 // anyway; a second barrier per k-tile) so that 3-5 workgroups stay resident per CU instead of 2 and one workgroup's
 // split/store phase overlaps another's MFMAs
-constexpr int lds_bufs(int tm, bool vec, int math) { return (math == 2 && (vec || tm >= 4)) ? 1 : 2; }
+constexpr int lds_bufs(int tm, bool vec, int math) { return math == 2 ? 1 : 2; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // The tile body is a device function so that ONE launch can mix two tile heights (conv_igemm_2phase_kernel below):
@@ -420,7 +420,8 @@ __device__ __forceinline__ void igemm_tile(
       // "is there a next tile": past the end the last tile is fetched / stored again (clamped index, nobody reads it), so
       // that the compiler can wait with exact vmcnt counts (a conditional fetch forces s_waitcnt vmcnt(0) at every use).
       auto body = [&](auto BUF, Fetch& Fin, Fetch& Fnew, int kt) __attribute__((always_inline)) {
-        constexpr int buf = decltype(BUF)::value;
+        constexpr int NB = lds_bufs(TM, VEC, MATH);
+        constexpr int buf = NB == 2 ? decltype(BUF)::value : 0;
         const int ktn = min(kt + 2, kt1 - 1);
         float4 bf[TN][NP], afc[NP], afn[NP];
   #pragma unroll
@@ -458,7 +459,8 @@ __device__ __forceinline__ void igemm_tile(
   #pragma unroll
           for (int q = 0; q < NP; ++q) afc[q] = afn[q];
         }
-        stash(Fin, buf ^ 1);
+        if (NB == 1) __syncthreads();                 // every wave is done reading the only buffer
+        stash(Fin, NB == 2 ? buf ^ 1 : 0);
         __syncthreads();
       };
       if (kt0 < kt1) {
