@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   // row pitch: 32 k = 128 B as fp32 or bf16 hi+lo, 192 B as bf16 hi+mid+lo; +16 B pad (36 r and 52 r mod 64 both walk all
   // 16 four-bank groups over 16 rows: conflict-free b128 fragment reads)
   constexpr int LDP = MATH == 2 ? 52 : LDW, NP = math_parts(MATH);
-  // bf16x6 rows are 1.5x as long: ONE LDS buffer (the next tile waits in registers anyway; costs a second barrier per
-  // k-tile) keeps two workgroups per CU for every tile shape, so that one's split/store phase overlaps the other's MFMAs
-  constexpr int NBUF = MATH == 2 ? 1 : 2;
+  // ONE LDS buffer for everything but the smallest fp32 tiles: the next tile waits in registers anyway, so the price is a
+  // second barrier per k-tile, and the 75-120 KB double-buffered tiles become 38-60 KB -- two (or more) workgroups per CU,
+  // so that one's load/split/store phase overlaps the other's MFMAs
+  constexpr int NBUF = (MATH == 0 && TM * TN <= 2) ? 2 : 1;
   __shared__ __attribute__((aligned(16))) float As[NBUF][BM][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[NBUF][BNW][LDP];
   __shared__ int2 Ts[BNW];
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     }
   } else {
   for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
+      const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
       const bool more = kt + 1 < kt1;
 #pragma unroll
       for (int t = 0; t < WBK / 8; ++t) {
@@ -394,7 +395,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
             __builtin_amdgcn_sched_barrier(0);
           }
       }
-      if (more) store_tiles(buf ^ 1);
+      if (NBUF == 1) __syncthreads();                   // every wave is done reading the only buffer
+      if (more) store_tiles(NBUF == 2 ? buf ^ 1 : 0);
       __syncthreads();
     }
 
