@@ -78,7 +78,7 @@ constexpr int lds_pitch(int math) { return math == 2 ? 28 : LDK; }
 // LDS buffers of the k-loop: the tall / 256-column bf16x6 tiles (96-byte rows) keep ONE (the next tile waits in registers
 // anyway; a second barrier per k-tile) so that 3-5 workgroups stay resident per CU instead of 2 and one workgroup's
 // split/store phase overlaps another's MFMAs
-constexpr int lds_bufs(int tm, bool vec, int math) { return math == 2 ? 1 : 2; }
+constexpr int lds_bufs(int tm, bool vec, int math) { return (math >= 1 || vec || tm >= 4) ? 1 : 2; }
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // The tile body is a device function so that ONE launch can mix two tile heights (conv_igemm_2phase_kernel below):
@@ -531,7 +531,8 @@ __device__ __forceinline__ void igemm_tile(
     }
   } else {
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int buf = (kt - kt0) & 1;
+      constexpr int NB = lds_bufs(TM, VEC, MATH);
+      const int buf = NB == 2 ? (kt - kt0) & 1 : 0;
       const bool more = kt + 1 < kt1;
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -553,7 +554,8 @@ __device__ __forceinline__ void igemm_tile(
             __builtin_amdgcn_sched_barrier(0);
           }
       }
-      if (more) store_tiles(buf ^ 1);
+      if (NB == 1) __syncthreads();                 // every wave is done reading the only buffer
+      if (more) store_tiles(NB == 2 ? buf ^ 1 : 0);
       __syncthreads();
     }
   }
