@@ -50,6 +50,33 @@ def test_geometry_validation_without_gpu(pkg):
     assert (int(t[26, 1]) >> 6) & 1 == 1 and int(t[26, 1]) & 63 == 8 and (int(t[27, 1]) >> 6) & 1 == 0 and int(t[27, 1]) & 63 == 63
 
 
+def test_conv_arithmetic_mode_is_an_accuracy_floor_host_side(pkg):
+    """gca_set_conv_math / tune_*_math (host logic only, no launch): the launch-configuration queries report the arithmetic
+    a pass would run with -- the mode in force, or a pinned one when that is at least as accurate (f32 > bf16x6 > bf16x3)."""
+    H = pkg._hip
+    import ctypes as C
+    g = H.ConvGeom(2, 16, 4, 8, 8, 40, 3, 3, 3, 1, 1, 1, 1, 1, 1, 4, 8, 8, 0)
+    out = (C.c_int32 * 4)()
+    math_of = lambda which: (H.lib.gca_conv_kernel_cfg(C.byref(g), which, out), (out[3] >> 12) & 3)[1] if which < 2 else \
+        (H.lib.gca_conv_wgrad_cfg(C.byref(g), out), (out[3] >> 12) & 3)[1]
+    default = H.lib.gca_get_conv_math()
+    try:
+        assert H.lib.gca_set_conv_math(3) == -1 and H.lib.gca_set_conv_math(-1) == -1
+        for mode in (0, 1, 2):
+            assert H.lib.gca_set_conv_math(mode) == 0 and H.lib.gca_get_conv_math() == mode
+            g.tune_fwd_math = g.tune_dgrad_math = g.tune_wgrad_math = 0
+            assert [math_of(w) for w in (0, 1, 2)] == [mode] * 3
+            for pin in (0, 1, 2):
+                g.tune_fwd_math = g.tune_dgrad_math = g.tune_wgrad_math = 1 + pin
+                rank = {0: 2, 2: 1, 1: 0}
+                want = pin if rank[pin] >= rank[mode] else mode
+                assert [math_of(w) for w in (0, 1, 2)] == [want] * 3, (mode, pin)
+        g.tune_fwd_math = 4
+        assert H.lib.gca_conv_kernel_cfg(C.byref(g), 0, out) == -1          # out of range: invalid geometry
+    finally:
+        H.lib.gca_set_conv_math(default)
+
+
 @pytest.mark.parametrize('name,octor', [('R2P1D18', lambda o: o.R2Plus1D(18)), ('S3D', lambda o: o.S3D()),
                                         ('R3D18', lambda o: o.R3D(18, 112, 16))])
 def test_backbones_match_oracle_state_dict(pkg, name, octor):
