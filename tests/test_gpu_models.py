@@ -210,12 +210,22 @@ def test_moco_two_step_trace_golden(pkg, golden, conv_math):
     assert int(tr.ptr_dev) == int(g.t('mo:ptr3')) == tr.contrast.index == 4
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('use_graph', [False, True])
-def test_moco_steps_vs_oracle(pkg, use_graph):
+def test_moco_steps_vs_oracle(pkg, use_graph, math):
     """5 MoCo iterations (hipGraph capture kicks in at the 3rd) incl. queue wrap, against the oracle run in
     fp64, next to the fp32 CPU oracle.  Forward / post-step state: 1e-3 max-norm.  Gradients: distribution
     bar of parity.check_grad_errors (isolated ReLU-boundary flips are inherent to fp32, see tests/parity.py);
     the HIP path must not be systematically worse than the fp32 CPU path."""
+    default = pkg.engine.ops.get_conv_math()
+    pkg.engine.ops.set_conv_math(math)
+    try:
+        _moco_steps_vs_oracle(pkg, use_graph)
+    finally:
+        pkg.engine.ops.set_conv_math(default)
+
+
+def _moco_steps_vs_oracle(pkg, use_graph):
     parity.register_tiny(pkg)
     gen = torch.Generator().manual_seed(5)
     imgs = [torch.randn(8, 6, 8, 48, 48, generator=gen) for _ in range(5)]
@@ -272,11 +282,21 @@ def test_temporal_graph_block_fwd_bwd_golden(pkg, golden, conv_math):
     assert rel_err(y2, g.t('aug:y_full_seed53')) < 1e-4
 
 
+@pytest.mark.parametrize('math', ['f32', 'bf16x6'])
 @pytest.mark.parametrize('use_graph', [False, True])
-def test_simsiam_trainer_steps_vs_oracle(pkg, use_graph):
+def test_simsiam_trainer_steps_vs_oracle(pkg, use_graph, math):
     """SimSiamTrainer (tape engine, fused SGD, hipGraph) against _train_simsiam restated by the oracle in fp64
     (tools/train_video_contrast_dis.py:479-523).  Teacher-forced like parity.run_moco_parity: every step starts
     from the fp64 run's parameters and momentum, so a step's error is that step's error."""
+    default = pkg.engine.ops.get_conv_math()
+    pkg.engine.ops.set_conv_math(math)
+    try:
+        _simsiam_trainer_steps_vs_oracle(pkg, use_graph)
+    finally:
+        pkg.engine.ops.set_conv_math(default)
+
+
+def _simsiam_trainer_steps_vs_oracle(pkg, use_graph):
     from oracle import moco as omoco, wrappers as owrap
     parity.register_tiny(pkg)
     cfg = parity.make_cfg(pkg, 'R2P1D10T', 'simsiam', 32, 16, 8)
