@@ -40,7 +40,7 @@ int gca_version(void);
  *   2  bf16x6:  three parts (x = hi + mid + lo to 2^-27) and the six products hh, hm, mh, hl, lh, mm: the dropped terms
  *               are <= 2^-25 relative, below fp32's own rounding -- fp32-grade results (same parity bars as mode 0 in
  *               tests/) at 2.7x less matrix-pipe time.
- * The default comes from the environment (GCA_CONV_MATH=f32|bf16x3|bf16x6, unset = f32).  GCA_EINVAL for another mode. */
+ * The default comes from the environment (GCA_CONV_MATH=f32|bf16x3|bf16x6, unset = bf16x6).  GCA_EINVAL for another mode. */
 int gca_set_conv_math(int mode);
 int gca_get_conv_math(void);
 

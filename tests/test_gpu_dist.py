@@ -70,7 +70,9 @@ def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph
     import dist_worker as w
     steps = 4
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0')
+    # GCA_CONV_MATH=f32: four UN-forced steps are a chaotic trajectory; the 3e-3 bar below is calibrated on how closely the
+    # fp32-MFMA kernels track fp64 (the split-product default is as accurate as the reference's fp32 CPU path, not more)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0', GCA_CONV_MATH='f32')
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
                                str(tmp_path), str(int(use_graph)), str(steps)], env=env) for r in range(world)]
     try:

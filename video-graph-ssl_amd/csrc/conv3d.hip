@@ -1077,7 +1077,7 @@ namespace gca_conv {
 int conv_math() {
   if (g_conv_math < 0) {
     const char* e = getenv("GCA_CONV_MATH");
-    g_conv_math = !e ? 0 : (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : (!strcmp(e, "bf16x6") || !strcmp(e, "2")) ? 2 : 0;
+    g_conv_math = !e ? 2 : (!strcmp(e, "bf16x3") || !strcmp(e, "1")) ? 1 : (!strcmp(e, "f32") || !strcmp(e, "0")) ? 0 : 2;
   }
   return g_conv_math;
 }
