@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
 
 // Split-K finishing pass, grid (channels, parts): sum the slabs in fixed order, add bias, (+=) store in
 // NCDHW (through the class's destination map), and emit the BN partial sums [K][parts].
-constexpr int FINISH_CHUNK = 4096;
+constexpr int FINISH_CHUNK = 1024;      // columns per finishing block: split-K grids are small, so many short blocks (4 columns per thread)
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
     const float* __restrict__ slab, int splits, const float* __restrict__ bias, float* __restrict__ dst,
     float* __restrict__ psum, float* __restrict__ psq, IgemmParams p) {
@@ -704,7 +704,15 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
   double s = 0.0, q = 0.0;
   for (long long n = lo + threadIdx.x; n < hi; n += 256) {
     float v = 0.f;
-    for (int k = 0; k < splits; ++k) v += slab[((long long)k * p.DK + m) * p.Ntot + n];
+    const float* sp0 = slab + (long long)m * p.Ntot + n;
+    const long long sstride = (long long)p.DK * p.Ntot;
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {               // four loads in flight, summed in the fixed order 0,1,2,...
+      const float l0 = sp0[(long long)k * sstride], l1 = sp0[(long long)(k + 1) * sstride];
+      const float l2 = sp0[(long long)(k + 2) * sstride], l3 = sp0[(long long)(k + 3) * sstride];
+      v += l0; v += l1; v += l2; v += l3;
+    }
+    for (; k < splits; ++k) v += sp0[(long long)k * sstride];
     s += (double)v; q += (double)v * (double)v;       // statistics of the conv output proper (no bias on that path)
     v += b;
     const int img = (int)(n / QSP);

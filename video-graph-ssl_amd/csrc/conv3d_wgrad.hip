@@ -434,8 +434,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
   const long long i = (long long)blockIdx.x * 64 + x;
   float s = 0.f;
-  if (i < n)
-    for (int k = y; k < splits; k += 4) s += slab[(long long)k * n + i];
+  if (i < n) {
+    int k = y;
+    for (; k + 12 < splits; k += 16) {              // four loads in flight per chain, summed in the fixed order
+      const float l0 = slab[(long long)k * n + i], l1 = slab[(long long)(k + 4) * n + i];
+      const float l2 = slab[(long long)(k + 8) * n + i], l3 = slab[(long long)(k + 12) * n + i];
+      s += l0; s += l1; s += l2; s += l3;
+    }
+    for (; k < splits; k += 4) s += slab[(long long)k * n + i];
+  }
   sh[y][x] = s;
   __syncthreads();
   if (y == 0 && i < n) {
