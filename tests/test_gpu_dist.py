@@ -65,14 +65,17 @@ def _simulate(pkg, world, steps, init, mem0, w):
     return reps, trace
 
 
-@pytest.mark.parametrize('world,use_graph', [(2, False), (2, True), (3, True)])
-def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph):
+@pytest.mark.parametrize('world,use_graph,math', [(2, False, 'f32'), (2, True, 'f32'), (3, True, 'f32'), (2, True, 'bf16x6')])
+def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph, math):
     import dist_worker as w
     steps = 4
     port = _free_port()
-    # GCA_CONV_MATH=f32: four UN-forced steps are a chaotic trajectory; the 3e-3 bar below is calibrated on how closely the
-    # fp32-MFMA kernels track fp64 (the split-product default is as accurate as the reference's fp32 CPU path, not more)
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0', GCA_CONV_MATH='f32')
+    # Four UN-forced steps are a chaotic trajectory; the 3e-3 bar on steps 2-3 and the parameter distribution bars below are
+    # calibrated on how closely the fp32-MFMA kernels track fp64.  The default arithmetic (bf16x6: as accurate as the
+    # reference's fp32 CPU path, not more) is held to the same 1e-3 on the two steps that run on (nearly) identical weights,
+    # to looser trajectory bars afterwards, and to the same bit-identical-replicas requirement.
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0', GCA_CONV_MATH=math)
+    late_bar, med_bar = (3e-3, 2e-4) if math == 'f32' else (5e-2, 5e-3)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
                                str(tmp_path), str(int(use_graph)), str(steps)], env=env) for r in range(world)]
     try:
@@ -92,7 +95,7 @@ def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph
                 err = parity.rel(torch.from_numpy(outs[r]['%s%d' % (key, s)]), trace[s][r][key])
                 # steps 0-1 run on (nearly) identical weights: the 1e-3 bar.  Later steps are NOT teacher-forced, they carry
                 # the ReLU-boundary gradient flips of the earlier updates (parity.py), so their bar is looser.
-                assert err < (1e-3 if s < 2 else 3e-3), (s, r, key, err)
+                assert err < (1e-3 if s < 2 else late_bar), (s, r, key, err)
     for r in range(world):
         model, ema, contrast, _ = reps[r]
         assert parity.rel(torch.from_numpy(outs[r]['mem']), contrast.memory) < 1e-3
@@ -104,7 +107,7 @@ def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph
                           if v.dtype.is_floating_point)
             # BN biases start at 0, so their error IS the accumulated relative gradient error of 4 steps; every step's
             # forward (loss, logits, q) above already holds the updated parameters to the 1e-3 bar.
-            assert errs[len(errs) // 2] < 2e-4 and errs[int(len(errs) * 0.9)] < 5e-2 and errs[-1] < 2e-1, \
+            assert errs[len(errs) // 2] < med_bar and errs[int(len(errs) * 0.9)] < 5e-2 and errs[-1] < 2e-1, \
                 (r, name, errs[len(errs) // 2], errs[int(len(errs) * 0.9)], errs[-1])
     # replicas stay bit-identical in their parameters (one all-reduce, same update)
     for k in outs[0].files:
