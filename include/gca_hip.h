@@ -66,7 +66,8 @@ typedef struct {
    * -- the reference does the same through cudnn.benchmark = True, tools/train_video_contrast_dis.py:50 --
    * and pins the winner here.  Results are deterministic for a fixed setting. */
   int32_t tune_fwd_bm, tune_fwd_splits;       /* tile rows 32..160 (x128 columns), | 1024 = x256 columns with float4
-                                                 gathers (pointwise-in-space convs only); split-K factor */
+                                                 gathers (pointwise-in-space convs only), | 2048 = LDS-halo kernel (tile
+                                                 box in tune_*_box); split-K factor */
   int32_t tune_dgrad_bm, tune_dgrad_splits;
   int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile shape index 1..10 (see gca_conv_wgrad_cfg), 0 = heuristic */
   int32_t tune_fwd_tail, tune_dgrad_tail;      /* two-phase launch: (short tile rows / 32) | (column tiles run with the tall
@@ -75,6 +76,10 @@ typedef struct {
                                                   pass with arithmetic m, honoured only when m is at least as accurate as
                                                   the mode in force (f32 > bf16x6 > bf16x3): the mode is a floor on
                                                   accuracy and the host pins whichever admissible kernel is fastest */
+  int32_t tune_fwd_box, tune_dgrad_box;        /* LDS-halo kernel (tune_*_bm & 2048): a tile is a box of bd x bh x bw output
+                                                  positions inside one clip, coded bd | bh << 8 | bw << 16 (powers of two,
+                                                  product 128 or 256); its input window is staged once per 16 channels in
+                                                  LDS and every tap is formed from there.  0 with the flag clear */
 } gca_conv_geom;
 
 /* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward
@@ -285,10 +290,17 @@ int gca_graph_gcn_bwd(const float* adj, const float* s, const float* dout, int64
  * configured by make_optimizer (lib/solver/build.py:24-59: one group per parameter).
  * ------------------------------------------------------------------------------------- */
 int gca_ema_update(float* p_ema, const float* p, int64_t n, float m, void* stream);
-/* seg table: per 256-element chunk i: lr[i], wd[i] (device arrays of length n/256). */
+/* seg table: per 256-element chunk i: lr[i], wd[i] (device arrays of length n/256).
+ * grad_clip: NULL, or the 2-float result of gca_grad_clip_coef -- every gradient is multiplied by grad_clip[1] on the
+ * fly (the grads.mul_(clip_coef) pass of clip_grad_norm_ without a pass over the arena). */
 int gca_sgd_step(float* p, const float* grad, float* mom_buf, int64_t n, const float* chunk_lr,
                  const float* chunk_wd, float lr_scale, float momentum, int nesterov, int first_step,
-                 void* stream);
+                 const float* grad_clip, void* stream);
+/* clip_grad_norm_(parameters, max_norm) of tools/train_video_contrast_dis.py:420-423 over the flat gradient arena
+ * (n % 4 == 0; padding elements are zero): out2[0] = total 2-norm, out2[1] = min(1, max_norm / (norm + 1e-6)).
+ * fp64 partial sums folded in a fixed order (deterministic); `ws` = gca_grad_clip_ws_bytes() bytes. */
+int64_t gca_grad_clip_ws_bytes(void);
+int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out2, void* ws, void* stream);
 int gca_fill(float* p, int64_t n, float v, void* stream);
 int gca_axpy(float* y, const float* x, int64_t n, float a, void* stream);          /* y += a*x */
 int gca_scale(float* y, int64_t n, float a, void* stream);

@@ -109,7 +109,7 @@ def set_key_encoder_mode(model_ema):
 
 
 def moco_train_step(model, model_ema, contrast, criterion, optimizer, images, alpha=0.999,
-                    shuffle_ids=None):
+                    shuffle_ids=None, clip_gradient=None):
     """One single-process iteration of _train_moco (tools/...dis.py:395-454).  With one
     process ShuffleBN (:189-231) reduces to: permute the key batch, encode, un-permute; all_k == k.
     Returns dict(loss, logits, q, k, prec1, prec5)."""
@@ -128,6 +128,8 @@ def moco_train_step(model, model_ema, contrast, criterion, optimizer, images, al
     logits, labels = contrast(feat_q, feat_k, all_k=all_k)
     loss = criterion(logits)
     loss.backward()
+    if clip_gradient is not None:                   # SOLVER.CLIP_GRADIENT != 'none' (:420-423)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_gradient)
     optimizer.step()
     prec1, prec5 = accuracy(logits.detach(), labels, topk=(1, 5))
     momentum_update(model, model_ema, alpha)
@@ -135,10 +137,12 @@ def moco_train_step(model, model_ema, contrast, criterion, optimizer, images, al
                 prec1=prec1, prec5=prec5)
 
 
-def simsiam_train_step(model, optimizer, images):
+def simsiam_train_step(model, optimizer, images, clip_gradient=None):
     """_train_simsiam (tools/...dis.py:479-523)."""
     optimizer.zero_grad()
     loss = model(images)
     loss.backward()
+    if clip_gradient is not None:                   # :496-499
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_gradient)
     optimizer.step()
     return dict(loss=loss.detach())

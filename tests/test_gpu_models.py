@@ -330,7 +330,7 @@ def _simsiam_trainer_steps_vs_oracle(pkg, use_graph):
             if 'running_' in k:
                 assert rel_err(v, rsd[k].float()) < 1e-3, (step, k)
     # Gradients: median per-tensor error 2e-5..5e-5 on a normal step.  With this seed step 2 has a pre-activation of
-    # 1.1e-5 (typical 0.95) at the LAST block's output ReLU (tests/diag_simsiam.py): the HIP forward, 1e-5 away from
+    # 1.1e-5 (typical 0.95) at the LAST block's output ReLU (tools/diag_simsiam.py): the HIP forward, 1e-5 away from
     # fp64 like any fp32 path, lands on the other side, and one flipped mask at the top of this 2048-element layer
     # moves every gradient below it by a few per cent.  A kernel bug would show on every step, a flip on one.
     assert sorted(medians)[2] < 2e-4 and max(medians) < 1e-1, medians
@@ -373,7 +373,7 @@ def test_full_width_encoder_backward_vs_fp64_oracle(pkg, name, math):
     """Forward AND backward of the full-width S3D (a3) and 3D-ResNet (a5) through the HIP engine against the oracle in
     fp64 on the same weights (the R(2+1)D family has its own step-level tests).  Features: 1e-3.  Gradients: through
     S3D's 77 BatchNorms, 13 max pools and ReLUs fp32 itself is chaotic -- the fp32 CPU oracle is 1e-2 (median over
-    parameter tensors) away from fp64 (tests/diag_s3d_bwd.py) -- so the HIP path is held to the fp32 oracle's OWN error
+    parameter tensors) away from fp64 (tools/diag_s3d_bwd.py) -- so the HIP path is held to the fp32 oracle's OWN error
     (x3), not to an absolute bar; the 3D-ResNet passes the absolute distribution bar of parity.check_grad_errors in fp32
     MFMA (median 7e-6: the fma chain + fp64 BN sums track fp64 far better than a standard fp32 implementation does -- the
     fp32 CPU oracle's own median is 5.8e-4).  bf16x6 is held, on both encoders, to the fp32 CPU oracle's own error (x3):

@@ -1,7 +1,7 @@
 """Diagnostic: gradient error of (a) the HIP path and (b) the fp32 CPU oracle, both against an fp64 CPU run."""
 import importlib, sys, os, copy, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import parity
 from oracle import moco as omoco, wrappers as owrap
 pkg = importlib.import_module('video-graph-ssl_amd')

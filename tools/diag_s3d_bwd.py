@@ -1,7 +1,7 @@
 """Diagnostic (not collected): S3D forward/backward per-parameter gradient error, HIP vs fp64 oracle vs fp32 oracle."""
 import importlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import parity
 from oracle import encoders as oenc
 pkg = importlib.import_module('video-graph-ssl_amd')

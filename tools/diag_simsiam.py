@@ -1,7 +1,7 @@
 """Diagnostic (not collected): per-parameter gradient error of teacher-forced SimSiam steps, HIP vs fp64 oracle."""
 import importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import parity
 from oracle import moco as omoco, wrappers as owrap
 pkg = importlib.import_module('video-graph-ssl_amd')

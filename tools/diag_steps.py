@@ -1,7 +1,7 @@
 """Diagnostic (not a test): per-key errors of the multi-step MoCo parity scenario."""
 import importlib, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import parity
 from oracle import moco as omoco
 pkg = importlib.import_module('video-graph-ssl_amd')

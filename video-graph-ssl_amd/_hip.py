@@ -31,7 +31,8 @@ class ConvGeom(C.Structure):
                                      'pd', 'ph', 'pw', 'OD', 'OH', 'OW')] + [('x_batch_stride', c_i64)] + \
                [(n, c_i32) for n in ('tune_fwd_bm', 'tune_fwd_splits', 'tune_dgrad_bm', 'tune_dgrad_splits',
                                      'tune_wgrad_splits', 'tune_wgrad_tile', 'tune_fwd_tail', 'tune_dgrad_tail',
-                                     'tune_fwd_math', 'tune_dgrad_math', 'tune_wgrad_math')]
+                                     'tune_fwd_math', 'tune_dgrad_math', 'tune_wgrad_math', 'tune_fwd_box',
+                                     'tune_dgrad_box')]
 
 
 class PoolGeom(C.Structure):
@@ -96,7 +97,9 @@ SIGNATURES = {
     'gca_graph_gcn_bwd_ws_bytes': (c_i64, [c_i64, c_i64, c_i64, c_i64]),
     'gca_graph_gcn_bwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'gca_ema_update': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
-    'gca_sgd_step': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_vp]),
+    'gca_sgd_step': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp]),
+    'gca_grad_clip_ws_bytes': (c_i64, []),
+    'gca_grad_clip_coef': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp]),
     'gca_fill': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
     'gca_axpy': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     'gca_scale': (c_i32, [c_vp, c_i64, c_f32, c_vp]),

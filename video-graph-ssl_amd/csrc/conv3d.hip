@@ -28,7 +28,7 @@
 // Reference call sites replaced: every nn.Conv3d / nn.Linear on the path (see include/gca_hip.h).
 #include <cstring>
 #include <type_traits>
-#include "conv_common.h"
+#include "conv_halo.h"
 
 #include <cstdlib>
 #include <vector>
@@ -37,28 +37,6 @@ using namespace gca_conv;
 
 namespace {
 
-struct IgemmParams {
-  int SC, SD, SH, SW;      // gathered (source) tensor: channels + spatial dims
-  int DK;                  // destination channels (GEMM M, un-padded)
-  int QD, QH, QW;          // iteration sub-grid (GEMM N = NB*QD*QH*QW)
-  int DD, DH, DW;          // destination tensor spatial dims
-  int dm_d, dm_h, dm_w;    // destination position = q*dm + do
-  int do_d, do_h, do_w;
-  int m_d, m_h, m_w;       // source position = q*m + o + tap delta
-  int o_d, o_h, o_w;
-  int ntaps;               // taps of this class (FAST: <= 62)
-  int Kpad, Mpad;
-  int tilesM, tilesN;
-  int tileN_off;           // first column tile of this launch (two-phase launches: tall tiles, then a short-tile tail)
-  int splits, kt_per_split;
-  int P;                   // stat partials per channel
-  int chk;                 // bit0: test D, bit1: test H, bit2: test W
-  int accumulate;
-  long long Ntot;
-  long long src_nstride;   // elements between consecutive images of the gathered tensor
-  unsigned src_bytes;      // extent of the gathered tensor for the buffer resource (range check)
-  unsigned dst_bytes;      // extent of the destination tensor
-};
 
 // ---------------------------------------------------------------------------------------------
 // 256 threads = 4 waves side by side along N: every wave owns all BM = 32*TM rows of the block tile and
@@ -735,13 +713,6 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
 // tap = ((kd0+sd*a)*KH + (kh0+sh*b))*KW + (kw0+sw*c).  fwd (which 0): value = W[m][ch][tap];
 // dgrad (which 1): value = W[ch][m][tap].  One thread per packed element, k fastest (coalesced writes; the
 // reads are contiguous for the forward layout and tap-strided for dgrad -- weights are L2-resident).
-struct PackParams {
-  int Kred, M, Kpad, Mrows;
-  int ntaps, nb, nc;           // class tap grid: ntaps = na*nb*nc
-  int k0d, k0h, k0w, sd, sh, sw;
-  int KH, KW, T;               // full kernel
-  long long s_ch, s_m;         // element strides of `ch` and `m` in W
-};
 __device__ __forceinline__ void pack_elements(const float* __restrict__ w, float* __restrict__ packed,
                                               const PackParams& p, long long first, long long step, long long end) {
   for (long long i = first; i < end; i += step) {
@@ -757,8 +728,12 @@ __device__ __forceinline__ void pack_elements(const float* __restrict__ w, float
   }
 }
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, PackParams p) {
-  pack_elements(w, packed, p, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x,
-                (long long)p.Mrows * p.Kpad);
+  if (p.fmt == 1)
+    pack_halo_elements(w, reinterpret_cast<unsigned char*>(packed), p, (long long)blockIdx.x * blockDim.x + threadIdx.x,
+                       (long long)gridDim.x * blockDim.x, pack_items(p));
+  else
+    pack_elements(w, packed, p, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x,
+                  pack_items(p));
 }
 
 // All convolutions of an encoder in ONE launch.  A job is one problem class of one layer; jobs own consecutive
@@ -784,135 +759,30 @@ __global__ __launch_bounds__(256) void conv_pack_batched_kernel(const unsigned c
   const PackParams p = j->p;
   const long long base = (long long)(bid - j->first_block) * PACK_CHUNK;
   long long end = base + PACK_CHUNK;
-  const long long total = (long long)p.Mrows * p.Kpad;
+  const long long total = pack_items(p);
   if (end > total) end = total;
-  pack_elements(j->w, j->packed, p, base + threadIdx.x, 256, end);
+  if (p.fmt == 1) pack_halo_elements(j->w, reinterpret_cast<unsigned char*>(j->packed), p, base + threadIdx.x, 256, end);
+  else pack_elements(j->w, j->packed, p, base + threadIdx.x, 256, end);
 }
 
 __global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 
-// ---- host side: problem classes ---------------------------------------------------------------
-struct ClassInfo {
-  int na, nb, nc, ntaps;        // tap grid of the class
-  int k0[3], ks[3];             // tap = k0 + ks*j per dim
-  int dl0[3], dls[3];           // gather delta of tap index j per dim: dl0 + dls*j
-  int q[3];                     // iteration sub-grid
-  int dm[3], dof[3];            // destination = q*dm + dof
-  int m[3], o[3];               // source = q*m + o + delta
-  int srcC, M;                  // gathered channels, GEMM M
-  long long Kred, Kpad;
-  long long table_off;          // int2 units inside the table buffer
-  long long pack_off;           // floats inside the packed buffer
-  bool vec;
+// ---- launch configuration ------------------------------------------------------------------
+struct IgemmCfg {
+  int bm; int bn; int splits; int kt_per_split; int tail_bm; int main_cols; int math;
+  int halo;              // 1: conv3d_halo.hip (LDS halo tiles); kt_per_split then counts 16-channel chunks
+  int bd, bh, bw;        // halo: box of a tile
 };
 
-inline int cdiv(int a, int b) { return (a + b - 1) / b; }
-inline int fast_of(int ntaps) { return ntaps <= 31 ? 1 : (ntaps <= FAST_MAX_TAPS ? 2 : 0); }
-inline int pack_rows(int M);
-
-// which: 0 forward, 1 dgrad
-void build_classes(const gca_conv_geom* g, int which, std::vector<ClassInfo>& out) {
-  const int kdim[3] = {g->kd, g->kh, g->kw}, sdim[3] = {g->sd, g->sh, g->sw}, pdim[3] = {g->pd, g->ph, g->pw};
-  const int in[3] = {g->D, g->H, g->W}, od[3] = {g->OD, g->OH, g->OW};
-  long long toff = 0, poff = 0;
-  auto finish = [&](ClassInfo& c) {
-    c.ntaps = c.na * c.nb * c.nc;
-    c.Kred = (long long)c.srcC * c.ntaps;
-    c.Kpad = gca_round_up(c.Kred, BK);
-    c.table_off = toff; c.pack_off = poff;
-    toff += c.Kpad + 32;                                   // rows + 64-int tap-delta table
-    poff += c.Kpad * pack_rows(c.M);
-    // VEC: rows are contiguous runs of the image -> no taps / stride / padding in H and W, float4-aligned planes
-    const int SH = which == 0 ? in[1] : od[1], SW = which == 0 ? in[2] : od[2];
-    c.vec = c.nb == 1 && c.nc == 1 && c.m[1] == 1 && c.m[2] == 1 && c.o[1] + c.dl0[1] == 0 && c.o[2] + c.dl0[2] == 0 &&
-            c.dm[1] == 1 && c.dm[2] == 1 && c.dof[1] == 0 && c.dof[2] == 0 && c.q[1] == SH && c.q[2] == SW &&
-            (SH * SW) % 4 == 0 && c.ntaps <= 31 &&
-            (which == 1 || g->x_batch_stride % 4 == 0);
-    out.push_back(c);
-  };
-  if (which == 0) {
-    ClassInfo c{};
-    c.na = g->kd; c.nb = g->kh; c.nc = g->kw;
-    for (int d = 0; d < 3; ++d) {
-      c.k0[d] = 0; c.ks[d] = 1; c.dl0[d] = 0; c.dls[d] = 1;
-      c.q[d] = od[d]; c.dm[d] = 1; c.dof[d] = 0; c.m[d] = sdim[d]; c.o[d] = -pdim[d];
-    }
-    c.srcC = g->C; c.M = g->K;
-    finish(c);
-    return;
-  }
-  // dgrad: one class per residue (rho_d, rho_h, rho_w) of the destination position modulo the stride
-  for (int rd = 0; rd < sdim[0]; ++rd)
-    for (int rh = 0; rh < sdim[1]; ++rh)
-      for (int rw = 0; rw < sdim[2]; ++rw) {
-        const int rho[3] = {rd, rh, rw};
-        ClassInfo c{};
-        int cnt[3];
-        bool empty = false;
-        for (int d = 0; d < 3; ++d) {
-          const int k0 = (rho[d] + pdim[d]) % sdim[d];
-          cnt[d] = k0 < kdim[d] ? (kdim[d] - 1 - k0) / sdim[d] + 1 : 0;
-          c.k0[d] = k0; c.ks[d] = sdim[d];
-          c.dl0[d] = (rho[d] + pdim[d] - k0) / sdim[d];    // exact
-          c.dls[d] = -1;                                    // next tap of the class is one source step back
-          c.q[d] = rho[d] < in[d] ? (in[d] - rho[d] + sdim[d] - 1) / sdim[d] : 0;
-          c.dm[d] = sdim[d]; c.dof[d] = rho[d];
-          c.m[d] = 1; c.o[d] = 0;
-          if (cnt[d] == 0 || c.q[d] == 0) empty = true;
-        }
-        c.na = cnt[0]; c.nb = cnt[1]; c.nc = cnt[2];
-        c.srcC = g->K; c.M = g->C;
-        if (empty) { c.na = c.nb = c.nc = 0; c.ntaps = 0; c.Kred = c.Kpad = 0; c.table_off = toff; c.pack_off = poff; c.vec = false; out.push_back(c); continue; }
-        finish(c);
-      }
-}
-
-inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, IgemmParams& p) {
-  if (which == 0) { p.SC = g->C; p.SD = g->D; p.SH = g->H; p.SW = g->W; p.DD = g->OD; p.DH = g->OH; p.DW = g->OW; }
-  else { p.SC = g->K; p.SD = g->OD; p.SH = g->OH; p.SW = g->OW; p.DD = g->D; p.DH = g->H; p.DW = g->W; }
-  p.DK = c.M;
-  p.QD = c.q[0]; p.QH = c.q[1]; p.QW = c.q[2];
-  p.dm_d = c.dm[0]; p.dm_h = c.dm[1]; p.dm_w = c.dm[2];
-  p.do_d = c.dof[0]; p.do_h = c.dof[1]; p.do_w = c.dof[2];
-  p.m_d = c.m[0]; p.m_h = c.m[1]; p.m_w = c.m[2];
-  p.o_d = c.o[0]; p.o_h = c.o[1]; p.o_w = c.o[2];
-  p.ntaps = c.ntaps;
-  p.Kpad = (int)c.Kpad; p.Mpad = (int)gca_round_up(c.M, MPAD);
-  p.Ntot = (long long)g->N * c.q[0] * c.q[1] * c.q[2];
-  p.src_nstride = which == 0 ? (g->x_batch_stride ? g->x_batch_stride : (long long)g->C * g->D * g->H * g->W)
-                             : (long long)g->K * g->OD * g->OH * g->OW;
-  {
-    const long long span = (long long)g->N * p.src_nstride * 4;
-    p.src_bytes = span > 0xfffff000LL ? 0xfffff000u : (unsigned)span;
-    const long long dspan = (long long)g->N * p.DK * p.DD * p.DH * p.DW * 4;     // destination tensor (or one slab)
-    p.dst_bytes = dspan > 0xfffff000LL ? 0xfffff000u : (unsigned)dspan;
-  }
-  // bounds tests: skip a dimension when every tap of every column stays inside by construction
-  const int lim[3] = {p.SD, p.SH, p.SW};
-  int chk = 0;
-  const int cn[3] = {c.na, c.nb, c.nc};
-  for (int d = 0; d < 3; ++d) {
-    const int dmin = c.dls[d] > 0 ? c.dl0[d] : c.dl0[d] + c.dls[d] * (cn[d] - 1);
-    const int dmax = c.dls[d] > 0 ? c.dl0[d] + c.dls[d] * (cn[d] - 1) : c.dl0[d];
-    const int lo = c.o[d] + dmin, hi = (c.q[d] - 1) * c.m[d] + c.o[d] + dmax;
-    if (lo < 0 || hi >= lim[d]) chk |= 1 << d;
-  }
-  p.chk = chk;
-}
-
-// ---- launch configuration ------------------------------------------------------------------
-struct IgemmCfg { int bm; int bn; int splits; int kt_per_split; int tail_bm; int main_cols; int math; };
-
-inline int pack_rows(int M) { return (int)gca_round_up(M, 32) + 128; }   // every tile height up to 160 stays in bounds
 
 // Heuristic default (the host side may override it per geometry after measuring: gca_conv_geom.tune_*).
 // Tile = 32*TM rows (TM = 1..5, picked to minimise padded rows) x 128 columns, or x 256 columns with float4
 // gathers for pointwise-in-space classes; the K loop is split when the tile grid cannot occupy the CUs and
 // the partial slabs stay small.  tune code: rows | 1024 for the 256-column variant.
 inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force_bm, int force_splits) {
-  IgemmCfg best{64, 128, 1, nk, 0, 0};
+  IgemmCfg best{64, 128, 1, nk, 0, 0, 0, 0, 0, 0, 0};
   double best_cost = 1e300;
   const bool force_vec = force_bm >= 1024;
   const int force_rows = force_bm & 1023;
@@ -942,22 +812,128 @@ inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force
       const double eff = (0.55 + 0.1 * tm) * (v ? 1.15 : 1.0) * occ;
       const double work = (double)bm * bn * per;
       const double cost = rounds * work / eff + (s > 1 ? 0.05 * rounds * work + 8.0 * bm * bn : 0.0);
-      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0, 0}; }
+      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0, 0, 0, 0, 0, 0}; }
     }
   }
   return best;
 }
 
-inline void tune_of(const gca_conv_geom* g, int which, int& fbm, int& fs, int& tail) {
-  if (which == 0) { fbm = g->tune_fwd_bm; fs = g->tune_fwd_splits; tail = g->tune_fwd_tail; }
-  else { fbm = g->tune_dgrad_bm; fs = g->tune_dgrad_splits; tail = g->tune_dgrad_tail; }
+inline void tune_of(const gca_conv_geom* g, int which, int& fbm, int& fs, int& tail, int& box) {
+  if (which == 0) { fbm = g->tune_fwd_bm; fs = g->tune_fwd_splits; tail = g->tune_fwd_tail; box = g->tune_fwd_box; }
+  else { fbm = g->tune_dgrad_bm; fs = g->tune_dgrad_splits; tail = g->tune_dgrad_tail; box = g->tune_dgrad_box; }
 }
 
+// ---- LDS-halo kernels (conv3d_halo.hip): geometry of a box tiling, eligibility, heuristic choice -------------------------
+inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// halo geometry of class c tiled by boxes (bd, bh, bw); false when the class / box cannot run on the halo kernels
+inline bool halo_geometry(const ClassInfo& c, const IgemmParams& p, int bd, int bh, int bw, int math, HaloParams& hp) {
+  if (c.ntaps < 1 || c.ntaps > 64 || c.srcC < 8) return false;
+  if (!is_pow2(bd) || !is_pow2(bh) || !is_pow2(bw)) return false;
+  const int bn = bd * bh * bw;
+  if (bn != 128 && bn != 256) return false;
+  const int cn[3] = {c.na, c.nb, c.nc}, b[3] = {bd, bh, bw};
+  int h[3], dmin[3];
+  for (int d = 0; d < 3; ++d) {
+    const int lo = c.dls[d] > 0 ? c.dl0[d] : c.dl0[d] + c.dls[d] * (cn[d] - 1);
+    const int hi = c.dls[d] > 0 ? c.dl0[d] + c.dls[d] * (cn[d] - 1) : c.dl0[d];
+    dmin[d] = lo;
+    h[d] = (b[d] - 1) * c.m[d] + (hi - lo) + 1;
+    if (lo < -127 || hi > 127) return false;
+  }
+  const long long P = (long long)h[0] * h[1] * h[2];
+  if (P > halo_max_positions()) return false;
+  hp.g = p;
+  hp.bd = bd; hp.bh = bh; hp.bw = bw; hp.lbh = ilog2(bh); hp.lbw = ilog2(bw);
+  hp.hd = h[0]; hp.hh = h[1]; hp.hw = h[2];
+  hp.h0d = c.o[0] + dmin[0]; hp.h0h = c.o[1] + dmin[1]; hp.h0w = c.o[2] + dmin[2];
+  hp.dmin_d = dmin[0]; hp.dmin_h = dmin[1]; hp.dmin_w = dmin[2];
+  hp.nbd = cdiv(c.q[0], bd); hp.nbh = cdiv(c.q[1], bh); hp.nbw = cdiv(c.q[2], bw);
+  hp.P = (int)P;
+  hp.nchunks = cdiv(c.srcC, 16);
+  hp.chunks_per_split = hp.nchunks;
+  hp.Mrows = pack_rows(c.M);
+  const long long cs = (long long)p.SD * p.SH * p.SW * 4;
+  const long long pk = (long long)hp.nchunks * c.ntaps * hp.Mrows * halo_row_bytes(math);
+  if (cs > 0x7fffffffLL || pk > 0xfffff000LL) return false;
+  hp.cs_bytes = (unsigned)cs;
+  hp.pack_bytes = (unsigned)pk;
+  return true;
+}
+
+// heuristic box for `bn` columns: least (padding of the iteration grid) x (halo positions per output), W runs >= 8 preferred
+inline bool halo_pick_box(const ClassInfo& c, const IgemmParams& p, int bn, int math, int& bd, int& bh, int& bw, double& cost_out) {
+  double best = 1e300;
+  for (int d = 1; d <= bn; d <<= 1)
+    for (int h = 1; d * h <= bn; h <<= 1) {
+      const int w = bn / (d * h);
+      if (d > 2 * c.q[0] || h > 2 * c.q[1] || w > 2 * c.q[2]) continue;      // at most one doubling past the grid
+      HaloParams hp;
+      if (!halo_geometry(c, p, d, h, w, math, hp)) continue;
+      const double cover = (double)cdiv(c.q[0], d) * d * cdiv(c.q[1], h) * h * (double)cdiv(c.q[2], w) * w /
+                           ((double)c.q[0] * c.q[1] * c.q[2]);
+      const double cost = cover * (1.0 + 0.08 * hp.P / bn) * (w >= 8 ? 1.0 : (w >= 4 ? 1.1 : 1.3));
+      if (cost < best) { best = cost; bd = d; bh = h; bw = w; }
+    }
+  cost_out = best;
+  return best < 1e299;
+}
+
+// tune code of a pass: rows (32..160) | 1024 = 256-column float4 variant | 2048 = LDS-halo kernel (box in tune_*_box:
+// bd | bh << 8 | bw << 16; bd*bh*bw = 128 or 256)
 inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, const IgemmParams& p, size_t nclasses) {
-  int fbm, fs, tail;
-  tune_of(g, which, fbm, fs, tail);
+  int fbm, fs, tail, box;
+  tune_of(g, which, fbm, fs, tail, box);
+  const int math = resolve_math(which == 0 ? g->tune_fwd_math : g->tune_dgrad_math);
+  // ---- LDS-halo kernel: forced by the tune code, or by the heuristic for multi-tap classes with enough channels and tiles
+  {
+    int bd = box & 255, bh = (box >> 8) & 255, bw = (box >> 16) & 255, rows = fbm & 1023;
+    bool use = false;
+    HaloParams hp;
+    if (fbm & 2048) {
+      use = bd > 0 && halo_geometry(c, p, bd, bh, bw, math, hp);
+    } else if (fbm == 0 && c.ntaps >= 3 && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
+      double cost = 0, cost2 = 0;
+      int d2, h2, w2;
+      const bool wide = p.DK <= 96 && halo_pick_box(c, p, 256, math, d2, h2, w2, cost2);
+      use = halo_pick_box(c, p, 128, math, bd, bh, bw, cost) && cost < 1.6;
+      if (wide && cost2 < 1.6 && (!use || cost2 <= cost * 1.05)) { bd = d2; bh = h2; bw = w2; use = true; }
+      if (use) use = halo_geometry(c, p, bd, bh, bw, math, hp);
+      rows = 0;
+    }
+    if (use) {
+      const int bn = bd * bh * bw, tmax = bn == 256 ? 3 : 5;
+      if (rows == 0) {                                   // fewest padded rows, taller tile on a tie
+        int bestpad = 1 << 30;
+        for (int tm = 1; tm <= tmax; ++tm) {
+          const int pad = cdiv(p.DK, 32 * tm) * 32 * tm;
+          if (pad <= bestpad) { bestpad = pad; rows = 32 * tm; }
+        }
+      }
+      if (rows >= 32 && rows <= 32 * (bn == 256 ? 4 : 5) && rows % 32 == 0 &&
+          halo_lds_bytes(rows, math, hp.P) <= (size_t)(160 << 10) - 1024) {
+        IgemmCfg cf{rows, bn, 1, hp.nchunks, 0, 0, math, 1, bd, bh, bw};
+        const long long tiles = (long long)cdiv(p.DK, rows) * g->N * hp.nbd * hp.nbh * hp.nbw;
+        int sp = 1;
+        if (fs > 0) sp = fs;
+        else if (tiles < 2 * NUM_CU && hp.nchunks >= 8 && (long long)p.DK * p.Ntot <= (1LL << 20)) {
+          long long want = gca_ceil_div(2 * NUM_CU, tiles);
+          if (want > hp.nchunks / 4) want = hp.nchunks / 4;
+          if (want > 16) want = 16;
+          if (want > 1) sp = (int)want;
+        }
+        if (sp > hp.nchunks) sp = hp.nchunks;
+        if (sp < 1) sp = 1;
+        cf.kt_per_split = cdiv(hp.nchunks, sp);
+        cf.splits = cdiv(hp.nchunks, cf.kt_per_split);
+        return cf;
+      }
+    }
+    if (fbm & 2048) { fbm = 0; fs = 0; tail = 0; }       // not runnable as asked: fall back to the gather kernels' heuristic
+  }
   IgemmCfg cf = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
-  cf.math = resolve_math(which == 0 ? g->tune_fwd_math : g->tune_dgrad_math);
+  cf.math = math;
   // Two-phase launch (measured configurations only; single-class passes, 128-column tiles, no split-K): the first
   // `main_cols` column tiles run with the tall tile, the rest with a short one -- the last, partly filled wave of tall
   // workgroups (up to a quarter of the launch time on the layer-1 shapes) becomes a full wave of short ones.
@@ -968,6 +944,10 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
     if (tb >= 32 && tb < cf.bm && mc > 0 && mc < tilesN) { cf.tail_bm = tb; cf.main_cols = mc; }
   }
   return cf;
+}
+
+inline long long halo_tiles_n(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& cf) {
+  return (long long)g->N * cdiv(c.q[0], cf.bd) * cdiv(c.q[1], cf.bh) * cdiv(c.q[2], cf.bw);
 }
 
 template <int TM, int BN, int FAST, bool VEC>
@@ -994,8 +974,9 @@ void launch_tm(const IgemmCfg& c, int fast, dim3 grid, hipStream_t st, const flo
   else launch_one<TM, 128, 0, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
 }
 
-inline int stat_parts(const IgemmCfg& c, long long Ntot) {
+inline int stat_parts(const IgemmCfg& c, long long Ntot, long long halo_tiles = 0) {
   if (c.splits > 1) return (int)gca_ceil_div(Ntot, FINISH_CHUNK);
+  if (c.halo) return (int)halo_tiles;
   return (int)gca_ceil_div(Ntot, c.bn);
 }
 
@@ -1060,6 +1041,30 @@ int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack,
   return gca_launch_status();
 }
 
+// One class on the LDS-halo kernels.  `tapdelta` = the 64-entry tap-delta table that follows the class's gather rows.
+int run_class_halo(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& cf, const float* src, const float* apack,
+                   const int2* table, const float* bias, float* dst, float* psum, float* psq, float* slab, IgemmParams p,
+                   hipStream_t st) {
+  HaloParams hp;
+  if (!halo_geometry(c, p, cf.bd, cf.bh, cf.bw, cf.math, hp)) return GCA_EINVAL;
+  if (cf.splits > 1 && !slab) return GCA_EINVAL;
+  hp.g.splits = cf.splits; hp.g.kt_per_split = cf.kt_per_split;
+  hp.chunks_per_split = cf.kt_per_split;
+  hp.g.tilesM = cdiv(p.DK, cf.bm);
+  const long long tn = halo_tiles_n(g, c, cf);
+  if (tn > 0x7fffffffLL) return GCA_EINVAL;
+  hp.g.tilesN = (int)tn; hp.g.tileN_off = 0;
+  hp.g.P = stat_parts(cf, p.Ntot, tn);
+  HaloCfg hc{cf.bm, cf.bn, cf.bd, cf.bh, cf.bw, cf.splits, cf.kt_per_split, cf.math};
+  int rc = halo_launch(hc, hp, src, reinterpret_cast<const unsigned char*>(apack), reinterpret_cast<const int*>(table + p.Kpad),
+                       bias, dst, cf.splits > 1 ? nullptr : psum, cf.splits > 1 ? nullptr : psq, slab, st);
+  if (rc || cf.splits == 1) return rc;
+  p.splits = cf.splits; p.P = hp.g.P;
+  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, cf.splits,
+                     bias, dst, psum, psq, p);
+  return gca_launch_status();
+}
+
 int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
   std::vector<ClassInfo> cls;
   build_classes(g, which, cls);
@@ -1107,12 +1112,18 @@ int64_t gca_conv_pack_elems(const gca_conv_geom* g, int which) {
   std::vector<ClassInfo> cls;
   build_classes(g, which, cls);
   int64_t n = 0;
-  for (const ClassInfo& c : cls) n += c.Kpad * pack_rows(c.M);
+  for (const ClassInfo& c : cls) n += pack_reserve(c);
   return n > 0 ? n : 64;
 }
 
-static void pack_params_of(const gca_conv_geom* g, int which, const ClassInfo& c, PackParams& p) {
+static void pack_params_of(const gca_conv_geom* g, int which, const ClassInfo& c, size_t nclasses, PackParams& p) {
   const int T = taps(g);
+  {
+    IgemmParams ip{};
+    class_params(g, which, c, ip);
+    const IgemmCfg cf = cfg_for(g, which, c, ip, nclasses);
+    p.fmt = cf.halo; p.math = cf.math; p.SC = c.srcC; p.nsteps = cdiv(c.srcC, 16) * c.ntaps;
+  }
   p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = (int)c.Kpad; p.Mrows = pack_rows(c.M);
   p.ntaps = c.ntaps; p.nb = c.nb; p.nc = c.nc;
   p.k0d = c.k0[0]; p.k0h = c.k0[1]; p.k0w = c.k0[2]; p.sd = c.ks[0]; p.sh = c.ks[1]; p.sw = c.ks[2];
@@ -1131,10 +1142,10 @@ int64_t gca_conv_pack_jobs_host(const gca_conv_geom* g, int which, const float* 
     if (jobs_out) {
       if (!w || !packed) return GCA_EINVAL;
       PackJob j{};
-      pack_params_of(g, which, c, j.p);
+      pack_params_of(g, which, c, cls.size(), j.p);
       j.w = w; j.packed = packed + c.pack_off;
       j.first_block = 0;
-      j.nblocks = (int)gca_ceil_div((long long)j.p.Mrows * j.p.Kpad, PACK_CHUNK);
+      j.nblocks = (int)gca_ceil_div(pack_items(j.p), PACK_CHUNK);
       unsigned char* dst = reinterpret_cast<unsigned char*>(jobs_out) + (size_t)n * GCA_PACK_JOB_BYTES;
       memset(dst, 0, GCA_PACK_JOB_BYTES);
       memcpy(dst, &j, sizeof(j));
@@ -1173,8 +1184,8 @@ int gca_conv_pack(const gca_conv_geom* g, int which, const float* w, float* pack
   for (const ClassInfo& c : cls) {
     if (c.ntaps == 0) continue;
     PackParams p{};
-    pack_params_of(g, which, c, p);
-    long long blocks = gca_ceil_div((long long)p.Mrows * p.Kpad, 256);
+    pack_params_of(g, which, c, cls.size(), p);
+    long long blocks = gca_ceil_div(pack_items(p), 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
                        packed + c.pack_off, p);
@@ -1251,7 +1262,7 @@ int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
     IgemmParams p{};
     class_params(g, which, c, p);
     const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12);
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | (cf.halo << 14);
     return GCA_OK;
   }
   return GCA_EINVAL;
@@ -1263,7 +1274,8 @@ int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g) {
   build_classes(g, 0, cls);
   IgemmParams p{};
   class_params(g, 0, cls[0], p);
-  return stat_parts(cfg_for(g, 0, cls[0], p, 1), p.Ntot);
+  const IgemmCfg cf = cfg_for(g, 0, cls[0], p, 1);
+  return stat_parts(cf, p.Ntot, cf.halo ? halo_tiles_n(g, cls[0], cf) : 0);
 }
 
 int64_t gca_conv_fwd_ws_bytes(const gca_conv_geom* g) { return geom_ok(g) ? ws_bytes_for(g, 0) : GCA_EINVAL; }
@@ -1279,7 +1291,11 @@ int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, con
   IgemmParams p{};
   class_params(g, 0, c, p);
   p.accumulate = 0;
-  return run_class(cfg_for(g, 0, c, p, 1), fast_of(c.ntaps), x, wpack, reinterpret_cast<const int2*>(table), bias,
+  const IgemmCfg cf = cfg_for(g, 0, c, p, 1);
+  if (cf.halo)
+    return run_class_halo(g, c, cf, x, wpack, reinterpret_cast<const int2*>(table), bias, y, stat_sum, stat_sq,
+                          reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
+  return run_class(cf, fast_of(c.ntaps), x, wpack, reinterpret_cast<const int2*>(table), bias,
                    y, stat_sum, stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
 }
 
@@ -1304,8 +1320,11 @@ int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, 
     IgemmParams p{};
     class_params(g, 1, c, p);
     p.accumulate = accumulate ? 1 : 0;
-    int rc = run_class(cfg_for(g, 1, c, p, cls.size()), fast_of(c.ntaps), dy, wpack + c.pack_off,
-                       tab + c.table_off, nullptr, dx, nullptr, nullptr, reinterpret_cast<float*>(ws), p, st);
+    const IgemmCfg cf = cfg_for(g, 1, c, p, cls.size());
+    int rc = cf.halo ? run_class_halo(g, c, cf, dy, wpack + c.pack_off, tab + c.table_off, nullptr, dx, nullptr, nullptr,
+                                      reinterpret_cast<float*>(ws), p, st)
+                     : run_class(cf, fast_of(c.ntaps), dy, wpack + c.pack_off,
+                                 tab + c.table_off, nullptr, dx, nullptr, nullptr, reinterpret_cast<float*>(ws), p, st);
     if (rc) return rc;
   }
   return GCA_OK;

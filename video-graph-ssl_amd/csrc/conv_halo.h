@@ -1,0 +1,72 @@
+// Interface between conv3d.hip (problem classes, launch configuration, C ABI) and conv3d_halo.hip (the LDS-halo kernels).
+#pragma once
+#include "conv_igemm_host.h"
+
+namespace gca_conv {
+
+// Kernel parameter block of conv_halo_kernel: the class description of conv3d.hip + the box tiling.
+struct HaloParams {
+  IgemmParams g;
+  int bd, bh, bw;        // box of iteration positions per tile, w fastest; powers of two, bd*bh*bw = tile columns
+  int lbh, lbw;          // log2(bh), log2(bw)
+  int hd, hh, hw;        // halo box (source positions) of a tile
+  int h0d, h0h, h0w;     // halo origin = box origin * m + h0   (h0 = o + smallest tap delta)
+  int dmin_d, dmin_h, dmin_w;   // smallest tap delta per dimension
+  int nbd, nbh, nbw;     // boxes per clip
+  int P;                 // hd*hh*hw valid halo positions (<= halo_max_positions()); LDS slot P is the dump slot
+  int nchunks, chunks_per_split;   // 16-channel chunks of the reduction
+  int Mrows;             // rows of one packed A step
+  unsigned cs_bytes;     // channel stride of the gathered tensor (bytes)
+  unsigned pack_bytes;   // extent of this class's packed weights
+};
+
+struct HaloCfg {
+  int bm, bn;            // tile rows (32..160), columns (128 | 256)
+  int bd, bh, bw;
+  int splits, chunks_per_split;
+  int math;
+};
+
+// One thread per (step, row, pair of channels) of the halo pack (PackParams fmt 1).
+__device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, unsigned char* __restrict__ packed,
+                                                   const PackParams& p, long long first, long long step, long long end) {
+  const int rowbytes = p.math == 2 ? 96 : 64;
+  for (long long i = first; i < end; i += step) {
+    const int kp = (int)(i & 7);                 // channel pair inside the chunk
+    const long long rowi = i >> 3;
+    const int m = (int)(rowi % p.Mrows);
+    const int s = (int)(rowi / p.Mrows);
+    const int chunk = s / p.ntaps, tl = s - chunk * p.ntaps;
+    const int a = tl / (p.nb * p.nc), r = tl - a * (p.nb * p.nc), b = r / p.nc, c = r - b * p.nc;
+    const int tap = ((p.k0d + p.sd * a) * p.KH + (p.k0h + p.sh * b)) * p.KW + (p.k0w + p.sw * c);
+    float v0 = 0.f, v1 = 0.f;
+    const int ch = chunk * 16 + 2 * kp;
+    if (m < p.M) {
+      if (ch < p.SC) v0 = w[(long long)ch * p.s_ch + tap + (long long)m * p.s_m];
+      if (ch + 1 < p.SC) v1 = w[(long long)(ch + 1) * p.s_ch + tap + (long long)m * p.s_m];
+    }
+    unsigned char* row = packed + rowi * rowbytes;
+    if (p.math == 0) {
+      *reinterpret_cast<float2*>(row + 8 * kp) = make_float2(v0, v1);
+    } else if (p.math == 2) {
+      unsigned h, md, l;
+      split_bf16x3(v0, v1, h, md, l);
+      *reinterpret_cast<unsigned*>(row + 4 * kp) = h;
+      *reinterpret_cast<unsigned*>(row + 32 + 4 * kp) = md;
+      *reinterpret_cast<unsigned*>(row + 64 + 4 * kp) = l;
+    } else {
+      unsigned h, l;
+      split_bf16x2(v0, v1, h, l);
+      *reinterpret_cast<unsigned*>(row + 4 * kp) = h;
+      *reinterpret_cast<unsigned*>(row + 32 + 4 * kp) = l;
+    }
+  }
+}
+
+inline int halo_row_bytes(int math) { return math == 2 ? 96 : 64; }
+size_t halo_lds_bytes(int bm, int math, int P);
+int halo_max_positions();
+int halo_launch(const HaloCfg& c, const HaloParams& hp, const float* src, const unsigned char* apack, const int* tapdelta,
+                const float* bias, float* dst, float* psum, float* psq, float* slab, hipStream_t st);
+
+}  // namespace gca_conv

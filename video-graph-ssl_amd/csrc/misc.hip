@@ -101,12 +101,15 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ pe, const 
 // One 256-element chunk per (lr, wd) pair: chunk c = i4 / 64.
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   long long n4, const float* __restrict__ clr, const float* __restrict__ cwd,
-                                                  float lr_scale, float mom, int nesterov, int first) {
+                                                  float lr_scale, float mom, int nesterov, int first,
+                                                  const float* __restrict__ gscale) {
+  const float gs = gscale ? gscale[1] : 1.f;       // clip coefficient of gca_grad_clip_coef (grads.mul_(coef) folded in)
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const long long c = i >> 6;
     const float lr = clr[c] * lr_scale, wd = cwd[c];
     float4 pv = reinterpret_cast<float4*>(p)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    if (gscale) { gv.x *= gs; gv.y *= gs; gv.z *= gs; gv.w *= gs; }
     float4 bv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(buf)[i];
     float d;
 #define GCA_SGD1(f)                                   \
@@ -118,6 +121,33 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
 #undef GCA_SGD1
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(buf)[i] = bv;
+  }
+}
+
+// clip_grad_norm_ (tools/train_video_contrast_dis.py:420-423; torch.nn.utils.clip_grad_norm_, 2-norm): per-block partial
+// sums of squares in fp64 over the whole gradient arena (padding elements are zero), then one block folds them in a fixed
+// order: out[0] = total_norm, out[1] = min(1, max_norm / (total_norm + 1e-6)).  Deterministic.
+constexpr int CLIP_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sqsum_partial_kernel(const float* __restrict__ g, long long n4, double* __restrict__ part) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  s = gca_block_sum256_d(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ part, int nparts, float max_norm,
+                                                        float* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = gca_block_sum256_d(s, sh);
+  if (threadIdx.x == 0) {
+    const float tn = (float)sqrt(s);
+    out[0] = tn;
+    out[1] = fminf(max_norm / (tn + 1e-6f), 1.0f);
   }
 }
 
@@ -194,10 +224,22 @@ int gca_ema_update(float* p_ema, const float* p, int64_t n, float m, void* strea
 }
 int gca_sgd_step(float* p, const float* grad, float* mom_buf, int64_t n, const float* chunk_lr,
                  const float* chunk_wd, float lr_scale, float momentum, int nesterov, int first_step,
-                 void* stream) {
+                 const float* grad_clip, void* stream) {
   if (!p || !grad || !mom_buf || !chunk_lr || !chunk_wd || n <= 0 || (n & 255)) return GCA_EINVAL;
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, grad, mom_buf,
-                     (long long)(n / 4), chunk_lr, chunk_wd, lr_scale, momentum, nesterov, first_step);
+                     (long long)(n / 4), chunk_lr, chunk_wd, lr_scale, momentum, nesterov, first_step, grad_clip);
+  return gca_launch_status();
+}
+int64_t gca_grad_clip_ws_bytes(void) { return (int64_t)CLIP_BLOCKS * (int64_t)sizeof(double); }
+int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out2, void* ws, void* stream) {
+  if (!grad || !out2 || !ws || n <= 0 || (n & 3) || !(max_norm > 0.f)) return GCA_EINVAL;
+  long long blocks = gca_ceil_div(n / 4, 256 * 8);
+  if (blocks > CLIP_BLOCKS) blocks = CLIP_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, (long long)(n / 4),
+                     reinterpret_cast<double*>(ws));
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double*>(ws),
+                     (int)blocks, max_norm, out2);
   return gca_launch_status();
 }
 int gca_fill(float* p, int64_t n, float v, void* stream) {

@@ -218,12 +218,12 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
     wp = conv.packed(plan, 0)
     train = bn.training
     if train:
-        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True)
+        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
         z, mean, invstd, scale, shift = ops.bn_train_fwd(ss, sq, N * SP, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,
                                                          bn.running_mean, bn.running_var, bn.num_batches_tracked, y,
                                                          None if residual is None else residual.t, relu, N, K, SP, out=out)
     else:
-        y = ops.conv_fwd(plan, x, wp, None)
+        y = ops.conv_fwd(plan, x, wp, None, w_raw=conv.weight.data)
         mean = invstd = None
         scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
         z = ops.bn_apply(y, scale, shift, None if residual is None else residual.t, relu, N, K, SP, out=out)
@@ -247,7 +247,7 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
             ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
             if xv.needs_grad:
                 buf, acc = xv.grad_buffer()
-                ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
+                ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc, w_raw=conv.weight.data)
         tape.record(back)
     return zv
 
@@ -259,7 +259,7 @@ def f_conv(tape, conv, xv):
     """Plain convolution (optional bias), no normalisation: temporal_graph.py:46,119-122."""
     x = xv.t
     plan = conv.plan(x)
-    y = ops.conv_fwd(plan, x, conv.packed(plan, 0), None if conv.bias is None else conv.bias.data)
+    y = ops.conv_fwd(plan, x, conv.packed(plan, 0), None if conv.bias is None else conv.bias.data, w_raw=conv.weight.data)
     yv = Var(y, tape.recording)
 
     def back():
@@ -271,7 +271,7 @@ def f_conv(tape, conv, xv):
             ops.bias_grad(dy, N, K, OD * OH * OW, _grad_of(conv.bias), True)
         if xv.needs_grad:
             buf, acc = xv.grad_buffer()
-            ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
+            ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc, w_raw=conv.weight.data)
     tape.record(back)
     return yv
 
@@ -281,7 +281,8 @@ def f_linear(tape, lin, xv):
     x = xv.t
     b = x.shape[0]
     plan = lin.plan(b, x.device)
-    y = ops.conv_fwd(plan, x, lin.packed(plan, 0), None if lin.bias is None else lin.bias.data).view(b, lin.out_features)
+    y = ops.conv_fwd(plan, x, lin.packed(plan, 0), None if lin.bias is None else lin.bias.data,
+                     w_raw=lin.weight.data).view(b, lin.out_features)
     yv = Var(y, tape.recording)
 
     def back():
@@ -292,7 +293,7 @@ def f_linear(tape, lin, xv):
             ops.bias_grad(dy, b, lin.out_features, 1, _grad_of(lin.bias), True)
         if xv.needs_grad:
             buf, acc = xv.grad_buffer()
-            ops.conv_dgrad(plan, dy, lin.packed(plan, 1), buf, acc)
+            ops.conv_dgrad(plan, dy, lin.packed(plan, 1), buf, acc, w_raw=lin.weight.data)
     tape.record(back)
     return yv
 
@@ -346,10 +347,10 @@ def f_conv_bn_relu_maxpool(tape, conv, bn, pool, xv):
     SP = OD * OH * OW
     wp = conv.packed(plan, 0)
     if bn.training:
-        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True)
+        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
         mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
     else:
-        y = ops.conv_fwd(plan, x, wp, None)
+        y = ops.conv_fwd(plan, x, wp, None, w_raw=conv.weight.data)
         mean = invstd = None
         scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
     pplan = ops.pool_plan(tuple(y.shape), pool.kernel_size, pool.stride, pool.padding)
@@ -368,7 +369,7 @@ def f_conv_bn_relu_maxpool(tape, conv, bn, pool, xv):
             ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
             if xv.needs_grad:
                 buf, acc = xv.grad_buffer()
-                ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc)
+                ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc, w_raw=conv.weight.data)
         tape.record(back)
     return pv
 

@@ -23,19 +23,33 @@ def _t3(v):
 # ----------------------------------------------------------------------------- workspace
 class _Workspace:
     """One grow-only scratch buffer per device.  All kernels run stream-ordered on the current
-    stream, so consecutive users never overlap in time."""
+    stream, so consecutive users never overlap in time.
+
+    A captured hipGraph holds the RAW pointer of the buffer it was recorded with.  A buffer that was handed out
+    during a capture is therefore never freed when a later (eager) caller needs more bytes: it is retired -- kept
+    alive next to the new, larger one -- so every existing graph keeps replaying into memory it still owns.
+    Growth is geometric, so the retired buffers sum to less than the live one."""
 
     def __init__(self):
         self.buf = {}
+        self.captured = set()       # keys whose current buffer has been baked into a graph
+        self.retired = []
 
     def get(self, nbytes, device):
         key = (device.type, device.index)
         b = self.buf.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         if b is None or b.numel() < nbytes:
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError('workspace would grow during graph capture; run one eager step first')
-            b = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+            if b is not None and key in self.captured:
+                self.retired.append(b)
+                self.captured.discard(key)
+            grown = 0 if b is None else b.numel() + b.numel() // 2
+            b = torch.empty(max(int(nbytes), grown, 1 << 20), dtype=torch.uint8, device=device)
             self.buf[key] = b
+        if capturing:
+            self.captured.add(key)
         return b
 
 
@@ -188,9 +202,56 @@ class ConvPlan:
                     cands.append((bm | vec, s))
         return cands
 
-    def tune(self, which, run):
+    def _halo_candidates(self, which, M):
+        """LDS-halo kernel candidates (tile code | 2048, split, box code): the few boxes with the least padding of the
+        output grid x halo size, each with the tile heights that pad M least.  Unit-stride dgrad and forward only."""
+        g = self.g
+        if which == 0:
+            q, m, C = (self.out_shape[2], self.out_shape[3], self.out_shape[4]), (g.sd, g.sh, g.sw), g.C
+        else:
+            if (g.sd, g.sh, g.sw) != (1, 1, 1):
+                return []
+            q, m, C = (g.D, g.H, g.W), (1, 1, 1), g.K
+        k = (g.kd, g.kh, g.kw)
+        if C < 16 or self.taps > 64:
+            return []
+        out = []
+        for bn, nbox in ((128, 3), (256, 2)):
+            boxes = []
+            d = 1
+            while d <= bn:
+                h = 1
+                while d * h <= bn:
+                    w = bn // (d * h)
+                    b = (d, h, w)
+                    if all(b[i] <= 2 * q[i] for i in range(3)):
+                        P = 1
+                        for i in range(3):
+                            P *= (b[i] - 1) * m[i] + k[i]
+                        if P <= 384:
+                            cover = 1.0
+                            for i in range(3):
+                                cover *= -(-q[i] // b[i]) * b[i] / q[i]
+                            cost = cover * (1.0 + 0.08 * P / bn) * (1.0 if w >= 8 else (1.1 if w >= 4 else 1.3))
+                            boxes.append((cost, b))
+                    h *= 2
+                d *= 2
+            boxes.sort()
+            tmax = 5 if bn == 128 else 3
+            pads = sorted((-(-M // (32 * t)) * 32 * t, -t) for t in range(1, tmax + 1))
+            rows = [32 * -t for _, t in pads[:2]]
+            for cost, b in boxes[:nbox]:
+                if cost > 2.0:
+                    continue
+                for bm in rows:
+                    out.append((bm | 2048, 1, b[0] | (b[1] << 8) | (b[2] << 16)))
+        return out
+
+    def tune(self, which, run, repack=None):
         """Measure the candidate launch configurations of pass `which` (0 fwd, 1 dgrad, 2 wgrad) with `run`
-        (a closure launching that pass on real operands) and pin the fastest."""
+        (a closure launching that pass on real operands) and pin the fastest.  `repack()` re-lays the packed weights
+        out for the configuration in force (the LDS-halo kernels read another layout than the gather kernels);
+        without it only configurations of the current layout are measured."""
         if self.tuned[which] or torch.cuda.is_current_stream_capturing():
             return
         self.tuned[which] = True
@@ -202,39 +263,59 @@ class ConvPlan:
         hit = _TUNE_CACHE.get(key)
 
         def apply(c):
-            # igemm: (tile code, splits, tail code, math code); wgrad: (tile shape, splits, math code); short = zeros
+            # igemm: (tile code, splits, tail code, math code, box code); wgrad: (tile shape, splits, math code); short = zeros
             if which == 0:
                 g.tune_fwd_bm, g.tune_fwd_splits = c[0], c[1]
                 g.tune_fwd_tail = c[2] if len(c) > 2 else 0
                 g.tune_fwd_math = c[3] if len(c) > 3 else 0
+                g.tune_fwd_box = c[4] if len(c) > 4 else 0
             elif which == 1:
                 g.tune_dgrad_bm, g.tune_dgrad_splits = c[0], c[1]
                 g.tune_dgrad_tail = c[2] if len(c) > 2 else 0
                 g.tune_dgrad_math = c[3] if len(c) > 3 else 0
+                g.tune_dgrad_box = c[4] if len(c) > 4 else 0
             else:
                 g.tune_wgrad_tile, g.tune_wgrad_splits = c[0], c[1]
                 g.tune_wgrad_math = c[2] if len(c) > 2 else 0
             self.refresh()
 
+        def layout():            # 1 = the pass reads the LDS-halo weight layout under the configuration in force
+            return (self.cfg(which)[3] >> 14) & 1 if which < 2 else 0
+
+        layout0 = layout()
         if hit is not None:
             apply(hit)
-            if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0:      # still a valid launch code for this library
-                return
-            apply((0, 0, 0, 0) if which < 2 else (0, 0, 0))
+            if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0 and (repack is not None or layout() == layout0):
+                if repack is not None and layout() != layout0:
+                    repack()
+                return                                             # still a valid launch code for this library
+            apply((0, 0, 0, 0, 0) if which < 2 else (0, 0, 0))
         if which == 0:
-            cands = self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)
+            cands = [c + (0,) for c in self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)]
+            cands += self._halo_candidates(0, K)
         elif which == 1:
-            cands = self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)
+            cands = [c + (0,) for c in self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)]
+            cands += self._halo_candidates(1, g.C)
         else:
             cands = self._wgrad_candidates(K, g.C * self.taps, -(-(N * OD * OH * OW) // 32))
         # The arithmetic mode is a floor on accuracy: a pass may run a MORE accurate kernel when that one is faster
         # (tune_*_math = 1 + arithmetic; f32 > bf16x6 > bf16x3).  0 = the mode itself.
         maths = {0: (0,), 2: (0, 1), 1: (0, 3, 1)}[H.lib.gca_get_conv_math()]
 
+        packed_as = [layout0]
+
         def measure(c):
             apply(c)
             if which == 2 and self.cfg(2)[3] & 255 != c[0]:      # shape not available for this tap count
                 return None
+            if which < 2:
+                if bool(c[0] & 2048) != bool(layout()):            # halo asked for but not runnable for this class
+                    return None
+                if layout() != packed_as[0]:
+                    if repack is None:
+                        return None
+                    repack()
+                    packed_as[0] = layout()
             try:
                 return _time_ms(run)
             except RuntimeError:
@@ -243,7 +324,7 @@ class ConvPlan:
         timed = []
         for m in maths:
             for c in cands:
-                c = (c[0], c[1], 0, m) if which < 2 else (c[0], c[1], m)
+                c = (c[0], c[1], 0, m, c[2]) if which < 2 else (c[0], c[1], m)
                 t = measure(c)
                 if t is not None:
                     timed.append((t, c))
@@ -269,7 +350,7 @@ class ConvPlan:
                     for tail_rows in (32, 64):
                         if tail_rows >= bm:
                             continue
-                        c = (bm, 1, (tail_rows // 32) | (main_cols << 8), m)
+                        c = (bm, 1, (tail_rows // 32) | (main_cols << 8), m, 0)
                         t = measure(c)
                         if t is not None:
                             timed.append((t, c))
@@ -280,7 +361,9 @@ class ConvPlan:
             _TUNE_DIRTY[0] = True
             apply(best)
         else:
-            apply((0, 0, 0, 0) if which < 2 else (0, 0, 0))
+            apply((0, 0, 0, 0, 0) if which < 2 else (0, 0, 0))
+        if which < 2 and layout() != packed_as[0]:
+            repack()
 
 
 @functools.lru_cache(maxsize=None)
@@ -309,11 +392,18 @@ def _conv_fwd_launch(plan, x, wpack, bias, y, ss, sq):
            ptr(ws), stream())
 
 
-def conv_fwd(plan, x, wpack, bias=None, stats=False):
-    """-> y [, (stat_sum, stat_sq)]  with stat layout [K][plan.parts]."""
+def _repacker(plan, which, w_raw, wpack):
+    if w_raw is None:
+        return None
+    return lambda: H.call('gca_conv_pack', plan.gp, which, ptr(w_raw), ptr(wpack), stream())
+
+
+def conv_fwd(plan, x, wpack, bias=None, stats=False, w_raw=None):
+    """-> y [, (stat_sum, stat_sq)]  with stat layout [K][plan.parts].  w_raw: the unpacked weights behind `wpack`; lets
+    the one-off launch tuning try configurations that read another packed layout (it re-packs into `wpack`)."""
     y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
     if not plan.tuned[0]:
-        plan.tune(0, lambda: _conv_fwd_launch(plan, x, wpack, bias, y, None, None))
+        plan.tune(0, lambda: _conv_fwd_launch(plan, x, wpack, bias, y, None, None), _repacker(plan, 0, w_raw, wpack))
     ss = sq = None
     if stats:
         ss = torch.empty((plan.g.K, plan.parts), dtype=F32, device=x.device)
@@ -328,13 +418,13 @@ def _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate):
            stream())
 
 
-def conv_dgrad(plan, dy, wpack_t, dx=None, accumulate=False):
+def conv_dgrad(plan, dy, wpack_t, dx=None, accumulate=False, w_raw=None):
     if dx is None:
         dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
         accumulate = False
     if not plan.tuned[1]:
         scratch = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
-        plan.tune(1, lambda: _conv_dgrad_launch(plan, dy, wpack_t, scratch, False))
+        plan.tune(1, lambda: _conv_dgrad_launch(plan, dy, wpack_t, scratch, False), _repacker(plan, 1, w_raw, wpack_t))
     _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate)
     return dx
 
@@ -609,9 +699,19 @@ def ema_update(p_ema, p, m):
     H.call('gca_ema_update', ptr(p_ema), ptr(p), p.numel(), float(m), stream())
 
 
-def sgd_step(p, g, buf, chunk_lr, chunk_wd, lr_scale, momentum, nesterov):
+def sgd_step(p, g, buf, chunk_lr, chunk_wd, lr_scale, momentum, nesterov, grad_clip=None):
+    """grad_clip: the (norm, coef) pair of grad_clip_coef -- gradients are scaled by coef inside the update."""
     H.call('gca_sgd_step', ptr(p), ptr(g), ptr(buf), p.numel(), ptr(chunk_lr), ptr(chunk_wd), float(lr_scale),
-           float(momentum), int(nesterov), 0, stream())
+           float(momentum), int(nesterov), 0, ptr(grad_clip), stream())
+
+
+def grad_clip_coef(g, max_norm, out=None):
+    """clip_grad_norm_ over the flat gradient arena -> device tensor (total_norm, clip coefficient)."""
+    if out is None:
+        out = torch.empty(2, dtype=F32, device=g.device)
+    ws = WS.get(H.lib.gca_grad_clip_ws_bytes(), g.device)
+    H.call('gca_grad_clip_coef', ptr(g), g.numel(), float(max_norm), ptr(out), ptr(ws), stream())
+    return out
 
 
 def fill(t, v):

@@ -12,6 +12,9 @@ Restates the iteration of tools/train_video_contrast_dis.py:395-454 (_train_moco
 Everything between the collectives is a fixed kernel sequence, so it is captured into hipGraphs
 (one for N=1; three segments around the collectives for N>1) and replayed per step.
 """
+import atexit
+import weakref
+
 import torch
 
 from . import ops
@@ -22,6 +25,7 @@ from .. import parallel as par
 from ..lib.memory import create_contrast, create_criterion
 from ..lib.modeling import create_visual_model
 from ..lib.solver import make_lr_scheduler, make_optimizer
+from ..lib.solver.build import clip_value_of
 
 
 def set_key_encoder_mode(model_ema):
@@ -32,11 +36,41 @@ def set_key_encoder_mode(model_ema):
             m.train()
 
 
+# Every live _Graphed, weakly: captured hipGraphs must be destroyed while the HIP runtime is still up.  A graph that is
+# only released by interpreter shutdown (a trainer held at module scope, the INTEGRATION.md usage) is torn down after the
+# runtime and aborts the process, so the package itself resets whatever is still alive from an atexit hook -- registered at
+# import, i.e. after torch's own hooks, and atexit runs last-registered first.
+_LIVE_GRAPHS = weakref.WeakSet()
+
+
+def release_all_graphs():
+    """Destroy every captured hipGraph of this process (idempotent).  Runs at interpreter exit; callable by hand."""
+    live = list(_LIVE_GRAPHS)
+    for g in live:
+        g.release()
+    if live and torch.cuda.is_available():
+        try:
+            torch.cuda.synchronize()
+        except RuntimeError:
+            pass
+
+
+atexit.register(release_all_graphs)
+
+
 class _Graphed(object):
     """Capture-once / replay wrapper for a no-argument closure working on static buffers."""
 
     def __init__(self, fn, enabled):
         self.fn, self.enabled, self.graph, self.warm = fn, enabled, None, 0
+        _LIVE_GRAPHS.add(self)
+
+    def release(self):
+        """Drop the captured graph (the next run() re-captures after its eager warm-up)."""
+        g, self.graph, self.warm = self.graph, None, 0
+        if g is not None:
+            torch.cuda.synchronize()
+            g.reset()
 
     def run(self):
         if not self.enabled:
@@ -56,9 +90,33 @@ class _Graphed(object):
         self.graph.replay()
 
 
-class MoCoTrainer(object):
+def _check_unsupported(cfg):
+    """Options the reference's trainer honours and this one does not must fail loudly, not train differently."""
+    apex = getattr(cfg, 'APEX', None)
+    if apex is not None and bool(getattr(apex, 'FLAG', False)):
+        raise NotImplementedError('APEX.FLAG (apex amp, tools/train_video_contrast_dis.py:134-141) is not available: '
+                                  'select the reduced-precision conv path with engine.ops.set_conv_math instead')
+
+
+class _TrainerBase(object):
+    def close(self):
+        """Release the captured hipGraphs now (they are re-captured if train_step is called again)."""
+        for g in (self._segments or []):
+            g.release()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
+class MoCoTrainer(_TrainerBase):
     def __init__(self, cfg, device, ctx=None, use_graph=True, seed=None):
+        _check_unsupported(cfg)
         self.cfg, self.device = cfg, torch.device(device)
+        self.clip = clip_value_of(cfg)
         self.ctx = ctx or par.DistCtx()
         if seed is not None:
             torch.manual_seed(seed)
@@ -146,7 +204,11 @@ class MoCoTrainer(object):
         self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
 
     def _phase_update(self):
-        self.optimizer.step()
+        clip = None
+        if self.clip is not None:                                             # :420-423, after the gradient all-reduce
+            clip = self.optimizer.clip_grad_norm(self.clip)
+            self.out['grad_norm'] = clip
+        self.optimizer.step(grad_clip=clip)
         ops.ema_update(self.arena_k.flat, self.arena_q.flat, self.alpha)      # :440
 
     def _single_gpu_all(self):
@@ -213,9 +275,11 @@ class MoCoTrainer(object):
         return int(sd.get('epoch', 0))
 
 
-class SimSiamTrainer(object):
+class SimSiamTrainer(_TrainerBase):
     def __init__(self, cfg, device, ctx=None, use_graph=True, seed=None):
+        _check_unsupported(cfg)
         self.cfg, self.device = cfg, torch.device(device)
+        self.clip = clip_value_of(cfg)
         self.ctx = ctx or par.DistCtx()
         if seed is not None:
             torch.manual_seed(seed)
@@ -242,11 +306,18 @@ class SimSiamTrainer(object):
             self._packer.release()
         self.out = dict(loss=lv.t)
 
+    def _update(self):
+        clip = None
+        if self.clip is not None:                              # tools/train_video_contrast_dis.py:497-500
+            clip = self.optimizer.clip_grad_norm(self.clip)
+            self.out['grad_norm'] = clip
+        self.optimizer.step(grad_clip=clip)
+
     def train_step(self, images):
         if self._static is None or self._static.shape != images.shape:
             self._static = torch.empty_like(images)
             self._packer = None
-            self._segments = [_Graphed(self._fwd_bwd, self.use_graph), _Graphed(self.optimizer.step, self.use_graph)]
+            self._segments = [_Graphed(self._fwd_bwd, self.use_graph), _Graphed(self._update, self.use_graph)]
         self._static.copy_(images)
         self.optimizer._sync_tables()
         self._segments[0].run()

@@ -6,8 +6,9 @@ at rows (index + i) % K (:17-27) and ``index`` advances (:14-15).  Device-agnost
 kernels run wherever the buffers live (GPU required).  Differences by design:
   * no K x D ``clone()`` per step: only the n rows about to be overwritten are saved, and the
     backward kernel reads those rows from the saved copy (same gradient as against the snapshot);
-  * `index` is ALSO kept in a registered buffer so it survives checkpoints (the reference loses it,
-    SURVEY.md section 5) -- the Python attribute stays authoritative for API compatibility.
+  * `index` stays a plain Python attribute and `state_dict()` holds `memory` only, exactly as in the reference
+    (so checkpoints load in both directions); the reference therefore loses the pointer on resume (SURVEY.md
+    section 5).  `MoCoTrainer.state_dict()` stores it next to the reference's keys as `queue_index`.
 """
 import torch
 import torch.nn as nn

@@ -42,10 +42,18 @@ class HipSGD(object):
         self.arena.rebind()
         ops.fill(self.arena.grad, 0.0)
 
-    def step(self):
+    def step(self, grad_clip=None):
+        """grad_clip: optional device (norm, coef) pair from clip_grad_norm(): the coefficient is applied to every
+        gradient inside the update kernel."""
         self._sync_tables()
         ops.sgd_step(self.arena.flat, self.arena.grad, self.buf, self.chunk_lr, self.chunk_wd, 1.0,
-                     self.momentum, self.nesterov)
+                     self.momentum, self.nesterov, grad_clip)
+
+    def clip_grad_norm(self, max_norm, out=None):
+        """torch.nn.utils.clip_grad_norm_ as the reference applies it between backward and step
+        (tools/train_video_contrast_dis.py:420-423), over the flat gradient arena, without a host sync: returns the
+        device pair (total_norm, coef); pass it to step(grad_clip=...) -- the gradients themselves are left unscaled."""
+        return ops.grad_clip_coef(self.arena.grad, max_norm, out)
 
     def state_dict(self):
         """torch.optim.SGD's wire format (what the reference checkpoints hold, tools/...dis.py:274-286): per-parameter
@@ -71,7 +79,26 @@ class HipSGD(object):
                              % (len(sd['param_groups']), len(self.param_groups)))
         for g, s_ in zip(self.param_groups, sd['param_groups']):
             g.update({k: v for k, v in s_.items() if k != 'params'})
+        # the update kernel takes ONE momentum / nesterov setting: re-read it from the loaded groups
+        moms = set(float(g.get('momentum', self.momentum)) for g in self.param_groups)
+        nest = set(bool(g.get('nesterov', self.nesterov)) for g in self.param_groups)
+        if len(moms) != 1 or len(nest) != 1:
+            raise NotImplementedError('per-group momentum / nesterov settings are not supported by the fused SGD kernel')
+        self.momentum, self.nesterov = moms.pop(), nest.pop()
         self._uploaded = None
+
+
+def clip_value_of(cfg):
+    """SOLVER.CLIP_GRADIENT: 'none' (every shipped YAML) or the max 2-norm (tools/train_video_contrast_dis.py:420)."""
+    v = getattr(cfg.SOLVER, 'CLIP_GRADIENT', 'none')
+    if isinstance(v, str):
+        if v.lower() == 'none':
+            return None
+        v = float(v)
+    v = float(v)
+    if not v > 0:
+        raise ValueError('SOLVER.CLIP_GRADIENT must be "none" or a positive max-norm (got %r)' % (v,))
+    return v
 
 
 def make_optimizer(cfg, model):
