@@ -115,6 +115,11 @@ int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
  * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask kind (0 none, 1: <=31 taps, 2: <=62)<<8 | float4-gather<<10 |
  *         arithmetic (0 f32, 1 bf16x3, 2 bf16x6)<<12}. */
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
+/* Signature of the packed-weight layout that pass `which` (0 fwd, 1 dgrad) reads under the launch configuration in force:
+ * one octal digit per problem class (0 = k-major fp32 rows of the gather kernels, 4 + arithmetic = the LDS-halo layout).
+ * A buffer packed by gca_conv_pack is valid exactly as long as this value does not change (the host re-packs when a
+ * tune_* field moves it). */
+int64_t gca_conv_pack_layout(const gca_conv_geom* g, int which);
 /* Layers whose output grid cannot fill the 256 CUs split the reduction over workgroups; the fp32
  * partial slabs live in `ws` (gca_conv_fwd_ws_bytes / gca_conv_dgrad_ws_bytes; 0 = not needed, ws may
  * then be NULL) and are summed in a fixed order (deterministic). */

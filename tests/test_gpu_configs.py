@@ -76,6 +76,7 @@ def test_configs1_moco_steps_under_tuned_launch_shapes(pkg, tuned_launch_shapes,
         sh = torch.randperm(b, generator=gen)
         _force_state(tr, m32, e32, c32, o32)
         before = {n: p.detach().clone() for n, p in m32.named_parameters()}
+        key_before = {n: p.detach().clone() for n, p in e32.named_parameters()}
         mem_before = c32.memory.clone()
         out = tr.train_step(images.to(DEV), shuffle_ids=sh)
         want = omoco.moco_train_step(m32, e32, c32, crit, o32, images, 0.999, shuffle_ids=sh)
@@ -96,9 +97,11 @@ def test_configs1_moco_steps_under_tuned_launch_shapes(pkg, tuned_launch_shapes,
         for k_, v in errs.items():
             assert v < (1e-3 if k_ != 'rank_rows_off' else 0.1), (math, step, k_, v)
             worst[k_] = max(worst.get(k_, 0.0), v)
-        # the update: (p_after - p_before) against the oracle's, per tensor.  Both sides are fp32 implementations (the oracle
-        # is as far from exact arithmetic as the kernels are: DESIGN.md, conv arithmetic modes), so this is a bar on the
-        # distribution -- it catches a tensor that is not updated, a wrong lr / weight-decay class, a stale momentum buffer
+        # the update: (p_after - p_before) against the oracle's, per tensor.  Both sides are fp32 implementations, and the
+        # gradients of this network move by 2e-2 (median over tensors; 1.5e-1 worst) when the clips are perturbed by 1e-6
+        # -- ReLU / max-pool decisions of activations within rounding of a tie (tools/grad_tuned_vs_heuristic.py --perturb;
+        # DESIGN.md).  So this is a bar on the distribution: it catches a tensor that is not updated, a wrong lr /
+        # weight-decay class, a stale momentum buffer, weights packed for another kernel layout (p90 0.67 when that happened)
         sd = tr.model.state_dict()
         upd = []
         for n, p in m32.named_parameters():
@@ -107,7 +110,7 @@ def test_configs1_moco_steps_under_tuned_launch_shapes(pkg, tuned_launch_shapes,
                 d_hip = (sd[n].detach().cpu() - before[n]).double()
                 upd.append(float((d_hip - d_ref).norm() / d_ref.norm()))
         upd.sort()
-        assert upd[len(upd) // 2] < 2e-2 and upd[int(0.9 * len(upd))] < 2e-1, (step, upd[len(upd) // 2], upd[-1])
+        assert upd[len(upd) // 2] < 5e-2 and upd[int(0.9 * len(upd))] < 2.5e-1, (step, upd[len(upd) // 2], upd[int(0.9 * len(upd))])
         # key encoder after the step: EMA'd parameters, and the BatchNorm running statistics its forward left behind (means on
         # the scale of the layer's standard deviation: the clips are zero-mean noise, so many batch means are pure rounding)
         esd, rsd = tr.model_ema.state_dict(), e32.state_dict()
@@ -115,8 +118,13 @@ def test_configs1_moco_steps_under_tuned_launch_shapes(pkg, tuned_launch_shapes,
             if k.endswith('running_mean'):
                 scale = rsd[k[:-4] + 'var'].sqrt().max()
                 assert float((v.cpu() - rsd[k]).abs().max() / scale) < 1e-3, (step, k)
-            elif v.dtype.is_floating_point and float(rsd[k].abs().max()) > 0:
+            elif k.endswith('running_var'):
                 assert rel_err(v, rsd[k]) < 1e-3, (step, k)
+        # EMA of the key encoder (tools/...dis.py:177-180) from the trainer's OWN query parameters: exact arithmetic check
+        qsd = dict(tr.model.named_parameters())
+        for n, pk in tr.model_ema.named_parameters():
+            want_k = key_before[n].to(DEV) * 0.999 + qsd[n].detach() * (1 - 0.999)
+            assert float((pk.detach() - want_k).abs().max()) <= 1e-4 * float(want_k.abs().max()) + 1e-12, (step, n)
         worst['update_median'] = max(worst.get('update_median', 0.0), upd[len(upd) // 2])
     # the plans really carry measured launch shapes (not the heuristic ones the rest of the suite runs on)
     tuned = total = 0

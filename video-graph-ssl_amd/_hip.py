@@ -52,6 +52,7 @@ SIGNATURES = {
     'gca_conv_table_build_host': (c_i32, [_GP, c_i32, c_vp]),
     'gca_conv_fwd_stat_parts': (c_i64, [_GP]),
     'gca_conv_kernel_cfg': (c_i32, [_GP, c_i32, c_vp]),
+    'gca_conv_pack_layout': (c_i64, [_GP, c_i32]),
     'gca_conv_fwd_ws_bytes': (c_i64, [_GP]),
     'gca_conv_fwd': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'gca_conv_dgrad_ws_bytes': (c_i64, [_GP]),

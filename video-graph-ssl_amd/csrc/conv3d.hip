@@ -824,6 +824,12 @@ inline void tune_of(const gca_conv_geom* g, int which, int& fbm, int& fs, int& t
 }
 
 // ---- LDS-halo kernels (conv3d_halo.hip): geometry of a box tiling, eligibility, heuristic choice -------------------------
+// GCA_HALO=0 keeps the un-tuned heuristic on the gather kernels (A/B runs; forced tune codes are still honoured)
+inline bool halo_heuristic_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GCA_HALO"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
@@ -893,7 +899,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
     HaloParams hp;
     if (fbm & 2048) {
       use = bd > 0 && halo_geometry(c, p, bd, bh, bw, math, hp);
-    } else if (fbm == 0 && c.ntaps >= 3 && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
+    } else if (fbm == 0 && halo_heuristic_on() && c.ntaps >= 3 && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
       double cost = 0, cost2 = 0;
       int d2, h2, w2;
       const bool wide = p.DK <= 96 && halo_pick_box(c, p, 256, math, d2, h2, w2, cost2);
@@ -1098,7 +1104,7 @@ int conv_math() {
 
 extern "C" {
 
-int gca_version(void) { return 8; }
+int gca_version(void) { return 9; }
 
 int gca_set_conv_math(int mode) {
   if (mode < 0 || mode > 2) return GCA_EINVAL;
@@ -1251,6 +1257,25 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* t) {
     }
   }
   return GCA_OK;
+}
+
+int64_t gca_conv_pack_layout(const gca_conv_geom* g, int which) {
+  if (!geom_ok(g) || which < 0 || which > 1) return GCA_EINVAL;
+  std::vector<ClassInfo> cls;
+  build_classes(g, which, cls);
+  int64_t sig = 0;
+  for (const ClassInfo& c : cls) {
+    int code = 0;                                  // 0: k-major fp32 rows; 4 + arithmetic: LDS-halo layout
+    if (c.ntaps) {
+      IgemmParams p{};
+      class_params(g, which, c, p);
+      const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
+      if (cf.halo) code = 4 + cf.math;
+    }
+    sig = sig * 8 + code;
+    if (sig > (1LL << 56)) sig %= 1000000007LL;    // (more than 18 classes: a hash is enough)
+  }
+  return sig;
 }
 
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {

@@ -17,6 +17,7 @@
 // BatchNorm partial sums by DPP, split-K slabs) as conv3d.hip.  Reference call sites: every nn.Conv3d with >= 16 input
 // channels (resnet2p1d.py:13-36,169-174; s3d_1.py:53-57; resnet.py:14-22,77-78).
 #include <cstring>
+#include <type_traits>
 #include "conv_igemm_host.h"
 #include "conv_halo.h"
 
@@ -31,8 +32,9 @@ constexpr int rowb(int math) { return math == 2 ? 96 : 64; }          // bytes o
 constexpr int pitchb(int math) { return rowb(math) + 16; }            // 80 / 112 B: odd number of 16-B slots -> conflict-free b128 reads
 constexpr int nparts(int math) { return math == 0 ? 1 : (math == 2 ? 3 : 2); }
 
+// (second launch bound = waves per SIMD: two workgroups per CU whenever the accumulators leave room for it)
 template <int TM, int TN, int MATH>
-__global__ __launch_bounds__(256) void conv_halo_kernel(
+__global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
     const float* __restrict__ src, const unsigned char* __restrict__ apack, const int* __restrict__ tapdelta,
     const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum, float* __restrict__ psq,
     float* __restrict__ slab, const HaloParams hp) {
@@ -178,65 +180,58 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // one (chunk, tap) step: this k-tile of 16 channels at one tap out of LDS
-  auto mma_step = [&](int buf, unsigned toff) __attribute__((always_inline)) {
-    const unsigned char* Ab = As + buf * (BM * PITCH) + aoff;
-    if constexpr (MATH == 0) {
+  // ---- fragments.  A fragment read is one ds_read_b128 of [row][part q][8 k of lane half]; for fp32 (MATH 0) the two
+  // reads q = 0, 1 are the k-steps 0..7 / 8..15 of the row (a lane of half h holds k = 8q + 4h + e).
+  constexpr int NQ = MATH == 0 ? 2 : NP;
+  float4 bfc[TN][NQ], afc[NQ], afn[NQ];
+  auto load_b = [&](float4 (&d)[TN][NQ], unsigned toff) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        float4 af[TM], bf[TN];
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Hs + bpos[j] + toff + 32 * t);
+      for (int q = 0; q < NQ; ++q) d[j][q] = *reinterpret_cast<const float4*>(Hs + bpos[j] + toff + 32 * q);
+  };
+  auto load_a = [&](float4 (&d)[NQ], int buf, int i) __attribute__((always_inline)) {
+    const unsigned char* Ab = As + buf * (BM * PITCH) + aoff + i * (32 * PITCH);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * PITCH + 32 * t);
+    for (int q = 0; q < NQ; ++q) d[q] = *reinterpret_cast<const float4*>(Ab + 32 * q);
+  };
+  auto mma_group = [&](int i, const float4 (&af)[NQ], const float4 (&bf)[TN][NQ]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+      if constexpr (MATH == 0) {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    } else {
-      float4 bf[TN][NP], afc[NP], afn[NP];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) bf[j][q] = *reinterpret_cast<const float4*>(Hs + bpos[j] + toff + 32 * q);
-#pragma unroll
-      for (int q = 0; q < NP; ++q) afc[q] = *reinterpret_cast<const float4*>(Ab + 32 * q);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (i + 1 < TM) {
-#pragma unroll
-          for (int q = 0; q < NP; ++q) afn[q] = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * PITCH + 32 * q);
+        for (int q = 0; q < 2; ++q) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[j][q].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].y, bf[j][q].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].z, bf[j][q].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].w, bf[j][q].w, acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const bf16x8 xh = __builtin_bit_cast(bf16x8, afc[0]), xl = __builtin_bit_cast(bf16x8, afc[NP - 1]);
-          const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
-          if (MATH == 2) {
-            const bf16x8 xm = __builtin_bit_cast(bf16x8, afc[1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
-          }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+      } else {
+        // bf16x3: x*y ~= xh*yh + xh*yl + xl*yh; bf16x6: hh + hm + mh + hl + lh + mm (conv3d.hip); fp32 accumulation
+        const bf16x8 xh = __builtin_bit_cast(bf16x8, af[0]), xl = __builtin_bit_cast(bf16x8, af[NQ - 1]);
+        const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NQ - 1]);
+        if (MATH == 2) {
+          const bf16x8 xm = __builtin_bit_cast(bf16x8, af[1]), ym = __builtin_bit_cast(bf16x8, bf[j][1]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int q = 0; q < NP; ++q) afc[q] = afn[q];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
       }
     }
   };
 
-  // ---- K loop: chunks [c0, c1) of this split, `ntaps` steps each; the A tiles form ONE sequence s = chunk*ntaps + tap
+  // ---- K loop: chunks [c0, c1) of this split, `ntaps` steps each; the A tiles form ONE sequence s = chunk*ntaps + tap that
+  // alternates between two LDS buffers (tile s+1 goes from registers to LDS behind the MFMAs of step s, the global loads of
+  // tile s+2 are issued right after; one barrier per step).  After the last tap of a chunk the next chunk's halo -- fetched
+  // while this chunk was being multiplied -- is split and written over the current one.
+  // (Measured and not kept: three A buffers with the fragments of step s+1 read during the MFMAs of step s and the halo
+  // re-staged inside the last step -- 40 more VGPRs, 50 % more LDS for A, 5-10 % slower on every layer shape.)
   const int c0 = split * hp.chunks_per_split;
   int c1 = c0 + hp.chunks_per_split; if (c1 > hp.nchunks) c1 = hp.nchunks;
   const int nt = p.ntaps;
@@ -248,28 +243,38 @@ __global__ __launch_bounds__(256) void conv_halo_kernel(
     halo_store();
     a_store(0);
     __syncthreads();                       // also publishes tapoff[]
-    a_issue(min(s + 1, s_end - 1));
-    halo_issue(min(c0 + 1, c1 - 1));       // unconditional fetches with a clamped index: exact vmcnt waits, no branches
-    int buf = 0;
-    for (int c = c0; c < c1; ++c) {
-      for (int t = 0; t < nt - 1; ++t) {
-        mma_step(buf, (unsigned)tapoff[t]);
-        a_store(buf ^ 1);                  // tile s+1 (fetched one step ago) -> the other buffer
-        a_issue(min(s + 2, s_end - 1));
-        __syncthreads();
-        buf ^= 1; ++s;
+    a_issue(min(s + 1, s_end - 1));        // unconditional fetches with a clamped index: exact vmcnt waits, no branches
+    halo_issue(min(c0 + 1, c1 - 1));
+    // ONE flat loop over the steps (a nested chunk / tap loop makes hipcc keep two copies of the accumulators and move
+    // all of them at every chunk boundary).  The tap offset of the NEXT step is read one step ahead, so no step starts
+    // with a dependent LDS read in front of its fragment reads.
+    int t = 0, c = c0, buf = 0;
+    unsigned toff = (unsigned)tapoff[0];
+    for (; s < s_end; ++s) {
+      const bool last_tap = t == nt - 1;
+      const unsigned toff_next = (unsigned)tapoff[last_tap ? 0 : t + 1];
+      load_b(bfc, toff);
+      load_a(afc, buf, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (i + 1 < TM) load_a(afn, buf, i + 1);
+        mma_group(i, afc, bfc);
+        if (i + 1 < TM) {
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) afc[q] = afn[q];
+        }
       }
-      // last tap of the chunk: afterwards the halo of the next chunk replaces this one
-      mma_step(buf, (unsigned)tapoff[nt - 1]);
-      a_store(buf ^ 1);
+      a_store(buf ^ 1);                    // tile s+1 (fetched one step ago) -> the other buffer
       a_issue(min(s + 2, s_end - 1));
-      __syncthreads();                     // every wave is done reading this chunk's halo
-      if (c + 1 < c1) {
+      __syncthreads();
+      if (last_tap && c + 1 < c1) {        // every wave is done reading this chunk's halo
         halo_store();
         halo_issue(min(c + 2, c1 - 1));
         __syncthreads();
       }
-      buf ^= 1; ++s;
+      buf ^= 1;
+      toff = toff_next;
+      if (last_tap) { t = 0; ++c; } else ++t;
     }
   }
 

@@ -53,7 +53,8 @@ inline int pack_rows(int M) { return (int)gca_round_up(M, 32) + 128; }   // ever
 // or [chunk][tap][row][<= 96 B] of the halo kernels), so that class offsets do not depend on the launch configuration
 inline long long pack_reserve(const ClassInfo& c) {
   const long long rows = pack_rows(c.M);
-  const long long flat = c.Kpad * rows, halo = (long long)cdiv(c.srcC, 16) * c.ntaps * rows * 24;
+  const long long flat = c.Kpad * rows;
+  const long long halo = c.srcC >= 8 && c.ntaps <= 64 ? (long long)cdiv(c.srcC, 16) * c.ntaps * rows * 24 : 0;   // halo_geometry()'s limits
   return halo > flat ? halo : flat;
 }
 

@@ -279,8 +279,10 @@ class ConvPlan:
                 g.tune_wgrad_math = c[2] if len(c) > 2 else 0
             self.refresh()
 
-        def layout():            # 1 = the pass reads the LDS-halo weight layout under the configuration in force
-            return (self.cfg(which)[3] >> 14) & 1 if which < 2 else 0
+        def layout():
+            """Packed-weight layout the pass reads under the configuration in force: 0 = k-major fp32 rows (gather
+            kernels), else the LDS-halo layout, which also depends on the arithmetic (fp32 rows / 2 / 3 bf16 parts)."""
+            return 0 if which == 2 else H.lib.gca_conv_pack_layout(self.gp, which)
 
         layout0 = layout()
         if hit is not None:
@@ -309,7 +311,7 @@ class ConvPlan:
             if which == 2 and self.cfg(2)[3] & 255 != c[0]:      # shape not available for this tap count
                 return None
             if which < 2:
-                if bool(c[0] & 2048) != bool(layout()):            # halo asked for but not runnable for this class
+                if bool(c[0] & 2048) != bool((self.cfg(which)[3] >> 14) & 1):       # halo asked for but not runnable here
                     return None
                 if layout() != packed_as[0]:
                     if repack is None:
@@ -362,7 +364,7 @@ class ConvPlan:
             apply(best)
         else:
             apply((0, 0, 0, 0, 0) if which < 2 else (0, 0, 0))
-        if which < 2 and layout() != packed_as[0]:
+        if which < 2 and repack is not None and layout() != packed_as[0]:
             repack()
 
 
@@ -381,7 +383,7 @@ def conv_plan(x_shape, K, k, s, p, device, x_batch_stride=0):
 def conv_pack(plan, which, w, out=None):
     n = plan.pack_elems[which]
     if out is None or out.numel() != n:
-        out = torch.empty(n, dtype=F32, device=w.device)
+        out = torch.zeros(n, dtype=F32, device=w.device)      # (room for either layout of the class; the unused part stays 0)
     H.call('gca_conv_pack', plan.gp, which, ptr(w), ptr(out), stream())
     return out
 
