@@ -229,50 +229,55 @@ def pmc_traffic(symbol):
     return None
 
 
-def infonce_timing(pkg, b=32):
+def infonce_timing(pkg, b=32, warm=False):
+    """InfoNCE forward (logits + row log-sum-exp + top-k rank + loss) at BASELINE's two queue sizes.  The call rotates over
+    enough DISTINCT queue / logits buffers that one lap exceeds the 256 MB Infinity Cache (MI355X_MICROARCH.md: scale past
+    L3 before reading bytes/s as HBM bandwidth): every launch streams its queue from HBM and writes logits that are not
+    resident.  Timed back to back inside one hipGraph (device time of the op, not of a graph launch)."""
     ops = pkg.engine.ops
     out = {}
     for K in (4096, 65536):
+        bytes_alg = K * 128 * 4 + 2 * b * 128 * 4 + b * (K + 1) * 4
+        nset = max(8, int(320e6 // bytes_alg) + 1) if not warm else 1      # warm: one buffer set replayed (cache-resident; diagnostics)
         q = torch.nn.functional.normalize(torch.randn(b, 128, device='cuda'))
         k = torch.nn.functional.normalize(torch.randn(b, 128, device='cuda'))
-        mem = torch.nn.functional.normalize(torch.randn(K, 128, device='cuda'))
-
-        def f():
-            ops.moco_logits_fwd(q, k, mem, 1 / 0.07, want_lse=True, want_rank=True, want_loss=True)   # logits, lse, rank, loss
-        g = torch.cuda.CUDAGraph()
-        f()
+        mems = [torch.nn.functional.normalize(torch.randn(K, 128, device='cuda')) for _ in range(nset)]
+        lgs = [torch.empty(b, K + 1, device='cuda') for _ in range(nset)]
+        ops.moco_logits_fwd(q, k, mems[0], 1 / 0.07, want_lse=True, want_rank=True, want_loss=True, logits=lgs[0])
         torch.cuda.synchronize()
-        REP = 20                                   # back to back inside one graph: device time of the op, not of a graph launch
+        g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(REP):
-                f()
-        ms = ev_time_ms(g.replay, 50, 5) / REP
-        bytes_alg = K * 128 * 4 + 2 * b * 128 * 4 + b * (K + 1) * 4
-        out['K%d' % K] = dict(ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2),
+            for i in range(nset * (20 if warm else 1)):
+                ops.moco_logits_fwd(q, k, mems[i % nset], 1 / 0.07, want_lse=True, want_rank=True, want_loss=True, logits=lgs[i % nset])
+        ms = ev_time_ms(g.replay, 20, 3) / (nset * (20 if warm else 1))
+        out['K%d' % K] = dict(ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2), distinct_buffer_sets=nset,
+                              working_set_MB=round(nset * bytes_alg / 1e6, 1),
                               GBps=round(bytes_alg / 1e9 / (ms / 1e3), 1),
                               hbm_frac=round(bytes_alg / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4))
+        del mems, lgs, g
     return out
 
 
 def graph_timing(pkg, B=4, C=192, T=8, HW=28):
     """Temporal-graph message passing (TemporalGraphAug GCN einsum + skip, temporal_graph.py:56-64) at the
     BASELINE configs[3] site: S3D base.5, (B,192,8,28,28), 8-node clip graph.  HBM-bound: read support +
-    write out = 2*B*C*T*H*W*4 bytes."""
+    write out = 2*B*C*T*H*W*4 bytes.  Rotates over distinct (support, out) pairs whose total exceeds the
+    256 MB Infinity Cache, so the GB/s are HBM traffic."""
     ops = pkg.engine.ops
-    s_ = torch.randn(B, C, T, HW, HW, device='cuda')
-    adj = torch.softmax(torch.randn(B, T, T, device='cuda'), -1)
-
-    def f():
-        ops.graph_gcn_fwd(adj, s_)
-    g = torch.cuda.CUDAGraph()
-    f()
-    torch.cuda.synchronize()
-    with torch.cuda.graph(g):
-        for _ in range(10):
-            f()
-    ms = ev_time_ms(g.replay, 50, 5) / 10
     bytes_alg = 2 * B * C * T * HW * HW * 4 + B * T * T * 4
-    return dict(shape=[B, C, T, HW, HW], ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2),
+    nset = max(8, int(320e6 // bytes_alg) + 1)
+    sup = [torch.randn(B, C, T, HW, HW, device='cuda') for _ in range(nset)]
+    outs = [torch.empty(B, C, T, HW, HW, device='cuda') for _ in range(nset)]
+    adj = torch.softmax(torch.randn(B, T, T, device='cuda'), -1)
+    ops.graph_gcn_fwd(adj, sup[0], outs[0])
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(nset):
+            ops.graph_gcn_fwd(adj, sup[i], outs[i])
+    ms = ev_time_ms(g.replay, 20, 3) / nset
+    return dict(shape=[B, C, T, HW, HW], ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2), distinct_buffer_sets=nset,
+                working_set_MB=round(nset * bytes_alg / 1e6, 1),
                 GBps=round(bytes_alg / 1e9 / (ms / 1e3), 1), hbm_frac=round(bytes_alg / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4),
                 gflops=round(2.0 * B * C * T * T * HW * HW / 1e9 / (ms / 1e3), 1))
 

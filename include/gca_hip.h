@@ -235,11 +235,14 @@ int gca_negcos_fwd_bwd(const float* p, const float* z, int64_t rows, int64_t dim
 /* logits (b, K+1).  Optional fused row statistics (any may be NULL): row_lse (b), rank_ge (b) = number of negatives
  * with logit >= the positive's (top-1 hit <=> 0, top-5 <=> < 5; lib/evaluation/metric.py:44-67 with label 0), and
  * loss (1) = NCESoftmaxLoss of these logits (needs row_lse) -- the whole forward of mem_moco.py:60-88 +
- * criterion.py:34-45 behind one call.  ws: gca_infonce_ws_bytes(b, K). */
+ * criterion.py:34-45 behind one call.  ws: gca_infonce_ws_bytes(b, K).
+ * sync_counter: one device uint32 that is ZERO before the first call (every call leaves it zero); with it, b <= 32 and
+ * D <= 128 the whole forward is ONE launch -- persistent waves stream the queue, the last workgroup to arrive folds the
+ * row statistics.  NULL selects the multi-launch path. */
 int64_t gca_infonce_ws_bytes(int64_t b, int64_t K);
 int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
                         int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge, float* loss,
-                        void* ws, void* stream);
+                        void* ws, uint32_t* sync_counter, void* stream);
 /* loss = mean_i (lse_i - logits[i,0]); lse computed here if row_lse_in == NULL. */
 int gca_nce_softmax_loss_fwd(const float* logits, int64_t b, int64_t ncol, const float* row_lse_in,
                              float* row_lse_out, float* loss, void* stream);

@@ -10,5 +10,6 @@ t = torch.cuda.Event(enable_timing=True); t2 = torch.cuda.Event(enable_timing=Tr
 t.record()
 for _ in range(40): a @ a
 t2.record(); torch.cuda.synchronize()
+import os
 for rep in range(3):
-    print(bench.infonce_timing(pkg, 32), flush=True)
+    print(bench.infonce_timing(pkg, 32, warm=os.environ.get('NCE_WARM', '0') == '1'), flush=True)

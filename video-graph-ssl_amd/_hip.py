@@ -82,7 +82,7 @@ SIGNATURES = {
     'gca_l2norm_bwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'gca_negcos_fwd_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f32, c_vp, c_i32, c_vp, c_vp]),
     'gca_infonce_ws_bytes': (c_i64, [c_i64, c_i64]),
-    'gca_moco_logits_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'gca_moco_logits_fwd': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'gca_nce_softmax_loss_fwd': (c_i32, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'gca_nce_softmax_loss_bwd': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_f32, c_vp, c_vp]),
     'gca_moco_logits_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_i64, c_i64, c_f32,

@@ -9,10 +9,12 @@
 // HBM-bound (AI ~ 12.7 F/B at b=32): algorithmic bytes = K*D*4 (queue) + b*(K+1)*4 (logits).
 // Reference: lib/memory/mem_moco.py:14-49,60-88; lib/memory/criterion.py:34-45.
 #include <cstdint>
+#include <cstdlib>
 #include "gca_common.h"
 #include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -214,6 +216,243 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_fused_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Whole InfoNCE forward in ONE launch for b <= 32 (a batch tile), D <= 128: logits, row log-sum-exp, top-k rank and the loss.
+//
+// Persistent waves: wave w of the launch owns the 32-row queue blocks w, w + nwaves, ...; the tile of the NEXT block is in
+// flight (16 float4 per lane) while the MFMAs of the current one run out of a wave-private LDS tile (no workgroup barrier in
+// the loop).  The soft-max statistics are kept PER LANE across all blocks of the wave -- running reference, sum of
+// exponentials and the count of negatives >= the positive, for each of the lane's 16 batch rows -- so the cross-lane
+// reductions (DPP) run once per wave, not once per block.  Workgroups then publish one (max, sum, count) triple per batch
+// row with write-through stores and draw a ticket from a device-scope counter; the workgroup that draws the last ticket
+// folds all partials (L1-bypassing loads), writes lse / rank / loss and re-arms the counter (cdna guide, Guideline 16:
+// counter form, sc1 payload).  `counter` must be zero before the first call and is left zero by every call.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
+    const float* __restrict__ q, const float* __restrict__ kpos, const float* __restrict__ queue,
+    int b, long long K, int D, float inv_T, float* __restrict__ logits, int ncb,
+    float* part, unsigned* counter, float* __restrict__ lse, int* __restrict__ rank, float* __restrict__ loss, gca_magic md4,
+    int dbg) {
+  constexpr int NT = FD / 8;
+  __shared__ __attribute__((aligned(16))) float Qs[32 * FP];
+  __shared__ __attribute__((aligned(16))) float Ns[WAVES][32 * FP];
+  __shared__ float L0[32];
+  __shared__ float Red[2 * WAVES][3][32];
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lh = lane >> 5, ll = lane & 31;
+  const int nwg = gridDim.x, nwaves = nwg * WAVES, gw = blockIdx.x * WAVES + wave;
+  const long long ld = K + 1;
+  const int d4 = D >> 2, nt = D >> 3;
+  float* Nw = Ns[wave];
+
+  // first queue tile of this wave: in flight while q is staged.  Every load of the kernel is UNCONDITIONAL: rows past the
+  // end go through the buffer resource's range check (all-ones offset -> 0.0), never through a branch -- a predicated load
+  // makes hipcc branch around it and wait for each one in turn (16 dependent HBM round trips per tile = 25 us).
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(queue), 0, (unsigned)(K * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(q), 0, (unsigned)(b * D * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kpos), 0, (unsigned)(b * D * 4), 0x00020000);
+  auto ld4 = [](const __amdgpu_buffer_rsrc_t& rs, unsigned off) __attribute__((always_inline)) {
+    const f32x4v f = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+    return make_float4(f.x, f.y, f.z, f.w);
+  };
+  float4 v[NT];
+  unsigned toff[NT];                  // byte offset of piece `it` inside a 32-row tile; all-ones for pieces past 32*d4
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const int i = lane + 64 * it, r = (int)gca_fdiv((unsigned)i, md4), c4 = i - r * d4;
+    toff[it] = i < 32 * d4 ? (unsigned)(r * D + c4 * 4) * 4u : 0xffffffffu;
+  }
+  auto fetch = [&](long long cb) __attribute__((always_inline)) {
+    const unsigned base = (unsigned)(cb * 32 * D * 4);              // rows past K fall outside the resource: zeros
+#pragma unroll
+    for (int it = 0; it < NT; ++it) v[it] = ld4(rq, toff[it] == 0xffffffffu ? 0xffffffffu : base + toff[it]);
+  };
+  long long cb = gw;
+  fetch(cb < ncb ? cb : 0);
+
+  {
+    constexpr int QPT = (32 * (FD / 4) + WAVES * 64 - 1) / (WAVES * 64);      // q pieces per thread
+    float4 qv[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+      const int i = tid + u * WAVES * 64;
+      const int m = (int)gca_fdiv((unsigned)i, md4), c4 = i - m * d4;
+      qv[u] = ld4(rb, i < 32 * d4 ? (unsigned)(m * D + c4 * 4) * 4u : 0xffffffffu);      // rows >= b: outside the resource
+    }
+#pragma unroll
+    for (int u = 0; u < QPT; ++u) {
+      const int i = tid + u * WAVES * 64;
+      const int m = (int)gca_fdiv((unsigned)i, md4), c4 = i - m * d4;
+      if (i < 32 * d4) *reinterpret_cast<float4*>(&Qs[m * FP + c4 * 4]) = qv[u];
+    }
+  }
+  __syncthreads();
+  if (!(dbg & 8)) {   // positive logits: 32 rows over WAVES waves, 64/(32/WAVES) lanes per row; all key loads up front
+    constexpr int RPW = WAVES >= 32 ? 1 : 32 / WAVES;
+    constexpr int LPR = 64 / RPW;
+    constexpr int PPL = (FD / 4 + LPR - 1) / LPR;                   // float4 pieces per lane
+    const int m = wave * RPW + lane / LPR, part_ = lane % LPR;
+    float4 kq[PPL];
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+      const int c4 = part_ + u * LPR;
+      kq[u] = ld4(rk, c4 < d4 ? (unsigned)(m * D + c4 * 4) * 4u : 0xffffffffu);
+    }
+    float sdot = 0.f;
+#pragma unroll
+    for (int u = 0; u < PPL; ++u) {
+      const int c4 = part_ + u * LPR;
+      if (c4 < d4) {
+        const float4 a = *reinterpret_cast<const float4*>(&Qs[m * FP + c4 * 4]);
+        sdot += a.x * kq[u].x + a.y * kq[u].y + a.z * kq[u].z + a.w * kq[u].w;
+      }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sdot += __shfl_xor(sdot, o, 64);
+    if (part_ == 0) L0[m] = sdot * inv_T;
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid < 32 && tid < b) logits[(long long)tid * ld] = L0[tid];
+
+  // per-lane statistics of the lane's 16 batch rows (row of register r: m = (r&3) + 8*(r>>2) + 4*lh)
+  float l0r[16], mx[16], sm[16], cn[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    l0r[r] = L0[(r & 3) + 8 * (r >> 2) + 4 * lh];
+    mx[r] = l0r[r]; sm[r] = 0.f; cn[r] = 0.f;
+  }
+
+  for (; cb < ncb; cb += nwaves) {
+    // registers -> this wave's LDS tile.  DS operations of one wave execute in order, so the fragment reads below see it
+    // and the next iteration's stores come after this iteration's reads: no barrier, no wait beyond the data dependences.
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const int i = lane + 64 * it, r = (int)gca_fdiv((unsigned)i, md4), c4 = i - r * d4;
+      if (i < 32 * d4) *reinterpret_cast<float4*>(&Nw[r * FP + c4 * 4]) = v[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    const long long nxt = cb + nwaves;
+    fetch(nxt < ncb ? nxt : cb);                   // unconditional (clamped): the next tile streams in behind the MFMAs
+    __builtin_amdgcn_wave_barrier();
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int t = 0; t < ((dbg & 4) ? 1 : nt); ++t) {
+      const float4 a = *reinterpret_cast<const float4*>(&Qs[ll * FP + 8 * t + 4 * lh]);
+      const float4 bq = *reinterpret_cast<const float4*>(&Nw[ll * FP + 8 * t + 4 * lh]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq.w, acc, 0, 0, 0);
+    }
+    const long long j = cb * 32 + ll;
+    const bool jv = j < K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float x = acc[r] * inv_T;
+      if (jv && i < b) {
+        logits[(long long)i * ld + 1 + j] = x;
+        if (dbg & 2) continue;
+        float d = x - mx[r];
+        if (d > 24.f) { sm[r] *= __expf(-d); mx[r] = x; d = 0.f; }       // rare: keeps exp(d) far from overflow
+        sm[r] += __expf(d);
+        cn[r] += x >= l0r[r] ? 1.f : 0.f;
+      }
+    }
+  }
+
+  // ---- one cross-lane fold per wave, then per workgroup
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float mh = half_wave_max_hi(mx[r]);
+    const float mxa = lh ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mh), 63))
+                         : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mh), 31));
+    const float se = half_wave_sum_hi_f(sm[r] * __expf(mx[r] - mxa));
+    const float ce = half_wave_sum_hi_f(cn[r]);
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (ll == 31) { Red[wave][0][m] = mxa; Red[wave][1][m] = se; Red[wave][2][m] = ce; }
+  }
+  __syncthreads();
+  if (dbg & 16) return;
+  if (tid < 32) {
+    float M = Red[0][0][tid];
+#pragma unroll
+    for (int w = 1; w < WAVES; ++w) M = fmaxf(M, Red[w][0][tid]);
+    float S = 0.f, C = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) { S += Red[w][1][tid] * __expf(Red[w][0][tid] - M); C += Red[w][2][tid]; }
+    // write-through (sc1) stores: visible to every other CU once this wave's vmcnt has drained -- no release fence
+    __hip_atomic_store(&part[(0 * nwg + blockIdx.x) * 32 + tid], M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[(1 * nwg + blockIdx.x) * 32 + tid], S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&part[(2 * nwg + blockIdx.x) * 32 + tid], C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains before the ticket is drawn
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = ticket == (unsigned)nwg - 1u;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  if (dbg & 1) { if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  // ---- last workgroup: fold every workgroup's partials (row = tid & 31; the 2*WAVES slices stride over the workgroups).
+  // The loads bypass L1 (sc1), which is what makes them see the other CUs' write-through stores without an acquire fence;
+  // sixteen workgroups' triples are in flight per thread (issued one dependent round trip at a time they cost 100 us for
+  // 256 workgroups).  Measured and not kept: agent-scope acquire + plain loads -- the fence alone cost 5-8 us here.
+  {
+    const int row = tid & 31, slice = tid >> 5;
+    float M = -INFINITY, S = 0.f, C = 0.f;
+    constexpr int UF = 16;
+    for (int g0 = slice; g0 < nwg; g0 += 2 * WAVES * UF) {
+      float pm_[UF], ps_[UF], pc_[UF];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        const int g = g0 + u * 2 * WAVES;
+        const int gc = g < nwg ? g : slice;                  // clamped: every load is issued, the surplus is ignored
+        pm_[u] = __hip_atomic_load(&part[(0 * nwg + gc) * 32 + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ps_[u] = __hip_atomic_load(&part[(1 * nwg + gc) * 32 + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pc_[u] = __hip_atomic_load(&part[(2 * nwg + gc) * 32 + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        if (g0 + u * 2 * WAVES < nwg) {
+          const float Mn = fmaxf(M, pm_[u]);
+          S = S * (M > -INFINITY ? __expf(M - Mn) : 0.f) + ps_[u] * __expf(pm_[u] - Mn);
+          M = Mn; C += pc_[u];
+        }
+      }
+    }
+    Red[slice][0][row] = M; Red[slice][1][row] = S; Red[slice][2][row] = C;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 2 * WAVES; ++w) M = fmaxf(M, Red[w][0][tid]);
+    float S = 0.f, C = 0.f;
+#pragma unroll
+    for (int w = 0; w < 2 * WAVES; ++w) {
+      if (Red[w][0][tid] > -INFINITY) S += Red[w][1][tid] * __expf(Red[w][0][tid] - M);
+      C += Red[w][2][tid];
+    }
+    const float l0 = L0[tid];
+    const float Mf = fmaxf(M, l0);
+    const float lsev = Mf + logf(S * __expf(M - Mf) + __expf(l0 - Mf));       // + the positive column
+    const bool rv = tid < b;
+    if (rv && lse) lse[tid] = lsev;
+    if (rv && rank) rank[tid] = (int)(C + 0.5f);
+    float term = rv ? lsev - l0 : 0.f;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) term += __shfl_xor(term, o, 64);
+    if (tid == 0 && loss) *loss = term / (float)b;
+    if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // re-arm for the next call
+  }
+}
+
 // one workgroup per batch row: fold the column-block partials and the positive column
 __global__ __launch_bounds__(256) void lse_finish_kernel(const float* __restrict__ logits, long long ld, int ncb,
                                                          const float* __restrict__ pm, const float* __restrict__ ps,
@@ -391,16 +630,47 @@ int64_t gca_infonce_ws_bytes(int64_t b, int64_t K) {
   if (b <= 0 || K <= 0) return GCA_EINVAL;
   // dq partial slabs: one (b x D) slab per BWD_RS-row queue slice, sized for the D <= 256 the
   // backward kernel accepts.
-  return (int64_t)sizeof(float) * gca_ceil_div(K, BWD_RS) * b * 256;
+  const int64_t dq = (int64_t)sizeof(float) * gca_ceil_div(K, BWD_RS) * b * 256;
+  const int64_t fwd = (int64_t)sizeof(float) * 3 * 32 * 2048;      // forward partials: (max, sum, count) x 32 rows x <= 2048 workgroups
+  return dq > fwd ? dq : fwd;
 }
 
 int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int64_t b, int64_t K,
                         int64_t D, float inv_T, float* logits, float* row_lse, int32_t* rank_ge, float* loss,
-                        void* ws, void* stream) {
+                        void* ws, uint32_t* sync_counter, void* stream) {
   if (!q || !k || !queue || !logits || b <= 0 || K <= 0 || D <= 0 || (D & 3)) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const bool want = row_lse || rank_ge || loss;
   if (loss && !row_lse) return GCA_EINVAL;          // the loss needs the row log-sum-exps (kept for the backward anyway)
+  static int persist_on = -1;
+  if (persist_on < 0) { const char* e = getenv("GCA_NCE_PERSIST"); persist_on = (e && e[0] == '0') ? 0 : 1; }     // A/B runs
+  if (persist_on && b <= 32 && D <= FD && (D & 7) == 0 && ws && sync_counter && K * D * 4 < 0xfffff000LL &&
+      (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)k) % 16) == 0) {
+    // single launch: persistent waves + last-arriving workgroup folds the statistics (moco_logits_persist_kernel)
+    const int ncb = (int)gca_ceil_div(K, 32);
+    static int env_waves = -1, env_grid = -1, env_dbg = 0;
+    if (env_waves < 0) {
+      const char* d_ = getenv("GCA_NCE_DEBUG"); env_dbg = d_ ? atoi(d_) : 0;      // timing experiments only (wrong results)
+      const char* e = getenv("GCA_NCE_WAVES"); env_waves = e ? atoi(e) : 0;
+      const char* g = getenv("GCA_NCE_GRID"); env_grid = g ? atoi(g) : 0;
+    }
+    // enough waves to cover the queue blocks, at most 4 per CU: past 1024 blocks every wave streams several tiles
+    int waves = ncb >= 64 ? 4 : (ncb >= 16 ? 2 : 1);       // (measured: 4 waves per workgroup at K = 4096 and at K = 65536)
+    if (env_waves == 1 || env_waves == 2 || env_waves == 4 || env_waves == 8) waves = env_waves;
+    long long grid = gca_ceil_div(ncb, waves);
+    if (grid > 256) grid = 256;
+    if (env_grid > 0) grid = env_grid;
+    const gca_magic md4 = gca_make_magic((unsigned)(D >> 2));
+    float* part = reinterpret_cast<float*>(ws);
+#define GCA_PERSIST(W) hipLaunchKernelGGL((moco_logits_persist_kernel<W>), dim3((unsigned)grid), dim3(64 * W), 0, st, q, k, queue, \
+                                          (int)b, (long long)K, (int)D, inv_T, logits, ncb, part, sync_counter, row_lse, rank_ge, loss, md4, env_dbg)
+    if (waves == 8) GCA_PERSIST(8);
+    else if (waves == 4) GCA_PERSIST(4);
+    else if (waves == 2) GCA_PERSIST(2);
+    else GCA_PERSIST(1);
+#undef GCA_PERSIST
+    return gca_launch_status();
+  }
   if (D <= FD && (D & 7) == 0 && (!want || ws) && (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)k) % 16) == 0) {
     // fused path: logits + LSE / rank partials in one pass over the queue, then a per-row fold
     const int ncb = (int)gca_ceil_div(K, 32);

@@ -600,19 +600,32 @@ def negcos(p, z, scale, loss_buf, accumulate):
 
 
 # ----------------------------------------------------------------------------- MoCo / InfoNCE
-def moco_logits_fwd(q, k, queue, inv_T, want_lse=False, want_rank=False, want_loss=False):
-    """-> (logits, lse, rank) [+ (loss,) when want_loss: the InfoNCE loss of these logits, fused into the same two
-    launches -- the separate nce_loss_fwd call is then unnecessary]."""
+_NCE_SYNC = {}
+
+
+def _nce_sync(device):
+    """The zero-initialised device counter of the single-launch InfoNCE forward (one per device; every call leaves it 0)."""
+    key = (device.type, device.index)
+    c = _NCE_SYNC.get(key)
+    if c is None:
+        c = _NCE_SYNC[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return c
+
+
+def moco_logits_fwd(q, k, queue, inv_T, want_lse=False, want_rank=False, want_loss=False, logits=None):
+    """-> (logits, lse, rank) [+ (loss,) when want_loss: the InfoNCE loss of these logits, fused into the same launch
+    (b <= 32) -- the separate nce_loss_fwd call is then unnecessary].  logits: optional (b, K+1) output buffer."""
     b, D = q.shape
     K = queue.shape[0]
     want_lse = want_lse or want_loss
-    logits = torch.empty((b, K + 1), dtype=F32, device=q.device)
+    if logits is None:
+        logits = torch.empty((b, K + 1), dtype=F32, device=q.device)
     lse = torch.empty(b, dtype=F32, device=q.device) if want_lse else None
     rank = torch.empty(b, dtype=torch.int32, device=q.device) if want_rank else None
     loss = torch.empty(1, dtype=F32, device=q.device) if want_loss else None
-    ws = WS.get(H.lib.gca_infonce_ws_bytes(b, K), q.device) if (want_lse or want_rank) else None
+    ws = WS.get(H.lib.gca_infonce_ws_bytes(b, K), q.device)
     H.call('gca_moco_logits_fwd', ptr(q), ptr(k), ptr(queue), b, K, D, float(inv_T), ptr(logits), ptr(lse), ptr(rank),
-           ptr(loss), ptr(ws), stream())
+           ptr(loss), ptr(ws), ptr(_nce_sync(q.device)), stream())
     return (logits, lse, rank, loss) if want_loss else (logits, lse, rank)
 
 
@@ -679,9 +692,10 @@ def graph_adj_bwd(dadj, gq, gk, sim, pre, adj, max_hop, alpha, temperature):
     return dgq, dgk
 
 
-def graph_gcn_fwd(adj, s):
+def graph_gcn_fwd(adj, s, out=None):
     B, Cc, T = s.shape[0], s.shape[1], s.shape[2]
-    out = torch.empty_like(s)
+    if out is None:
+        out = torch.empty_like(s)
     H.call('gca_graph_gcn_fwd', ptr(adj), ptr(s), B, Cc, T, s.shape[3] * s.shape[4], ptr(out), stream())
     return out
 
