@@ -11,12 +11,18 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import tape as _tape
 from .tape import Var
+
+
+GRAD_LOG = None        # a list while a trainer maps parameters to backward closures: (closure index, parameter)
 
 
 def _grad_of(p):
     if p.grad is None:
         p.grad = torch.zeros_like(p.data)
+    if GRAD_LOG is not None:
+        GRAD_LOG.append((_tape.CURRENT[0], p))
     return p.grad
 
 

@@ -33,6 +33,9 @@ class Var:
             ops.axpy(self.grad, g, 1.0)
 
 
+CURRENT = [-1]        # index of the closure being run by Tape.backward (read by the gradient log of engine/layers.py)
+
+
 class Tape:
     def __init__(self, recording):
         self.recording = recording
@@ -42,6 +45,11 @@ class Tape:
         if self.recording:
             self.fns.append(fn)
 
-    def backward(self):
-        while self.fns:
+    def backward(self, upto=0):
+        """Run the recorded closures in reverse, down to (and including) index `upto`.  Calling it again with a smaller
+        index continues where the previous call stopped: the multi-GPU trainer runs the backward pass in stages and
+        starts the all-reduce of a gradient bucket as soon as the last closure that writes into it has been issued."""
+        while len(self.fns) > upto:
+            CURRENT[0] = len(self.fns) - 1
             self.fns.pop()()
+        CURRENT[0] = -1

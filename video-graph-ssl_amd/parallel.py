@@ -117,6 +117,100 @@ def allreduce_sum_(flat, ctx):
     return flat
 
 
+class BucketReducer(object):
+    """Gradient all-reduce in arena buckets, overlapped with the backward pass (what DDP does with its 25 MB buckets,
+    tools/train_video_contrast_dis.py:143,419 -- here a few LARGE buckets: xGMI rings are per-link bound, so fewer,
+    larger collectives win).  `launch(lo, hi)` starts the SUM all-reduce of flat[lo:hi] without blocking the host; the
+    collective runs on the process group's own stream behind everything already queued on the current stream, so the
+    backward kernels of the next stage overlap it.  `wait()` makes the current stream wait for all of them."""
+
+    def __init__(self, flat, ctx):
+        self.flat, self.ctx, self.pending = flat, ctx, []
+
+    def launch(self, lo, hi):
+        if not self.ctx.active or hi <= lo:
+            return
+        view = self.flat[lo:hi]
+        if self.ctx.host_staged:                       # gloo rehearsal on one GPU: synchronous, through the host
+            h = view.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.ctx.group)
+            view.copy_(h)
+        else:
+            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.ctx.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()                                   # stream-side wait: the host does not block
+        self.pending = []
+
+
+def plan_buckets(first_closure, offsets, sizes, total, target_elems):
+    """Partition the flat gradient arena [0, total) into contiguous buckets of about `target_elems` elements and give
+    each the index of the backward closure after which it is complete.  first_closure[i] = smallest tape index that
+    writes parameter i's gradient (None: never written).  Returns [(closure index, lo, hi)] sorted by closure index
+    DESCENDING -- the order in which a reverse sweep of the tape completes them."""
+    n = len(offsets)
+    bounds, acc = [total], 0
+    for i in range(n - 1, -1, -1):                     # walk the arena from its end (the head: finished first)
+        acc += (offsets[i + 1] if i + 1 < n else total) - offsets[i]
+        if acc >= target_elems and i > 0:
+            bounds.append(offsets[i])
+            acc = 0
+    bounds.append(0)
+    bounds = sorted(set(bounds))
+    out = []
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        idx = [first_closure[i] for i in range(n) if lo <= offsets[i] < hi and first_closure[i] is not None]
+        out.append((min(idx) if idx else 0, lo, hi))
+    out.sort(key=lambda b: -b[0])
+    return out
+
+
+class ExchangePlans(object):
+    """ShuffleBN index bookkeeping for step t prepared while step t-1 runs: the permutation comes from the shared seed
+    (no broadcast), the send / place / un-shuffle indices are built on the host ahead of time and uploaded through
+    pinned memory with non-blocking copies, so nothing but the collectives sits between the trainer's graph segments."""
+
+    def __init__(self, b, ctx, seed, device):
+        self.b, self.ctx, self.seed, self.device = b, ctx, seed, device
+        self.cache = {}
+
+    def _build(self, step, shuffle_ids=None):
+        b, ctx = self.b, self.ctx
+        ids = shared_permutation(b * ctx.world, self.seed, step) if shuffle_ids is None else shuffle_ids
+        send_idx, send_counts, recv_counts, place_idx = exchange_plan(ids, b, ctx.rank, ctx.world)
+        rev = torch.argsort(ids)[ctx.rank * b:(ctx.rank + 1) * b]
+        up = lambda t: (t.pin_memory() if t.numel() else t).to(self.device, non_blocking=True)
+        return dict(ids=ids, send_idx=up(send_idx), place_idx=up(place_idx), unshuffle_idx=up(rev),
+                    send_counts=send_counts, recv_counts=recv_counts)
+
+    def get(self, step, shuffle_ids=None):
+        if shuffle_ids is not None:
+            return self._build(step, shuffle_ids)
+        p = self.cache.pop(step, None)
+        return p if p is not None else self._build(step)
+
+    def prefetch(self, step):
+        if step not in self.cache:
+            self.cache[step] = self._build(step)
+
+
+def shuffle_exchange_planned(x, plan, ctx, gather):
+    """shuffle_exchange with the indices already on the device (ExchangePlans)."""
+    b = x.shape[0]
+    send = gather(x, plan['send_idx']) if plan['send_idx'].numel() else x[:0]
+    recv = torch.empty((b,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if ctx.host_staged:
+        recv_h = torch.empty(recv.shape, dtype=x.dtype)
+        dist.all_to_all_single(recv_h, send.contiguous().cpu(), output_split_sizes=plan['recv_counts'],
+                               input_split_sizes=plan['send_counts'], group=ctx.group)
+        recv.copy_(recv_h)
+    else:
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=plan['recv_counts'],
+                               input_split_sizes=plan['send_counts'], group=ctx.group)
+    return gather(recv, plan['place_idx'])
+
+
 def broadcast_(t, ctx, src=0):
     """Initial queue / parameter sync (:233-241)."""
     if ctx.active:
