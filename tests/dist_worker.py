@@ -35,6 +35,9 @@ def main():
     ctx = pkg.parallel.DistCtx(rank, world, host_staged=True)
     # different seeds per rank: the initial broadcast from rank 0 must make the replicas identical
     tr = pkg.MoCoTrainer(cfg, 'cuda:0', ctx=ctx, use_graph=use_graph, seed=123 + rank)
+    tr.bucket_elems = int(os.environ.get('GCA_BUCKET_ELEMS', '60000'))     # tiny model: ~8 gradient buckets (0 = one all-reduce)
+    if tr.bucket_elems <= 0:
+        tr.bucket_elems = 1 << 40
     out = {}
     if rank == 0:
         for k, v in tr.model.state_dict().items():
@@ -54,6 +57,7 @@ def main():
     out['mem'] = tr.contrast.memory.detach().cpu().numpy()
     out['index'] = np.array(tr.contrast.index)
     out['ptr_dev'] = tr.ptr_dev.cpu().numpy()
+    out['n_buckets'] = np.array(len(tr._buckets))
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), **out)
     dist.barrier()
     dist.destroy_process_group()

@@ -114,3 +114,34 @@ def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph
         if k.startswith('final/') and 'running' not in k and 'num_batches' not in k:
             assert all(np.array_equal(outs[0][k], outs[r][k]) for r in range(1, world)), k
     assert all(np.array_equal(outs[0]['mem'], outs[r]['mem']) for r in range(1, world))
+
+
+def _run_workers(tmp, world, use_graph, steps, extra_env):
+    import dist_worker as w          # noqa: F401  (constants)
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0', GCA_CONV_MATH='f32', **extra_env)
+    os.makedirs(tmp, exist_ok=True)
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
+                               tmp, str(int(use_graph)), str(steps)], env=env) for r in range(world)]
+    try:
+        rcs = [p.wait(timeout=420) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert rcs == [0] * world
+    return [np.load(os.path.join(tmp, 'rank%d.npz' % r)) for r in range(world)]
+
+
+def test_bucketed_overlapped_allreduce_is_bit_identical_to_single(pkg, tmp_path):
+    """The staged backward (one graph segment per gradient bucket, all-reduce of a bucket issued as soon as the last
+    closure that writes into it has run) against ONE all-reduce over the whole gradient arena after the backward pass:
+    same trajectory bit for bit at two ranks (a + b is the same sum whichever bucket carries it), graphs and all."""
+    steps = 5                                            # 1 un-staged planning step, 2 eager staged, capture, replay
+    a = _run_workers(str(tmp_path / 'bucketed'), 2, True, steps, {'GCA_BUCKET_ELEMS': '30000'})
+    b = _run_workers(str(tmp_path / 'single'), 2, True, steps, {'GCA_BUCKET_ELEMS': '0'})
+    assert int(a[0]['n_buckets']) >= 3 and int(b[0]['n_buckets']) == 1
+    for r in range(2):
+        for k in a[r].files:
+            if k != 'n_buckets':
+                assert np.array_equal(a[r][k], b[r][k]), (r, k)

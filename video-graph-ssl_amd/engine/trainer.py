@@ -17,6 +17,7 @@ import weakref
 
 import torch
 
+from . import layers as L
 from . import ops
 from .arena import arena_of
 from .layers import BatchedPacker
@@ -61,8 +62,8 @@ atexit.register(release_all_graphs)
 class _Graphed(object):
     """Capture-once / replay wrapper for a no-argument closure working on static buffers."""
 
-    def __init__(self, fn, enabled):
-        self.fn, self.enabled, self.graph, self.warm = fn, enabled, None, 0
+    def __init__(self, fn, enabled, pool=None):
+        self.fn, self.enabled, self.graph, self.warm, self.pool = fn, enabled, None, 0, pool
         _LIVE_GRAPHS.add(self)
 
     def release(self):
@@ -84,7 +85,7 @@ class _Graphed(object):
             # with a process group alive, its watchdog thread polls events while we capture: only THIS thread's
             # calls must be checked against the capture (the default "global" mode would fail the capture)
             mode = 'thread_local' if torch.distributed.is_available() and torch.distributed.is_initialized() else 'global'
-            with torch.cuda.graph(g, capture_error_mode=mode):        # records the launches, does not execute them
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):    # records the launches, does not execute them
                 self.fn()
             self.graph = g
         self.graph.replay()
@@ -98,7 +99,20 @@ def _check_unsupported(cfg):
                                   'select the reduced-precision conv path with engine.ops.set_conv_math instead')
 
 
+BUCKET_ELEMS = 8 << 20        # gradient all-reduce bucket: 8 M fp32 = 32 MB (four buckets for R(2+1)D-18 + head)
+
+
 class _TrainerBase(object):
+    def _buckets_from_log(self, arena, log):
+        """log: (backward closure index, parameter) pairs of one eager backward pass (engine.layers.GRAD_LOG).  Cuts the
+        arena into buckets that a reverse sweep of the tape completes one after the other (parallel.plan_buckets)."""
+        first = {}
+        for idx, prm in log:
+            if idx >= 0:
+                first[id(prm)] = min(first.get(id(prm), idx), idx)
+        fc = [first.get(id(prm)) for prm in arena.params]
+        return par.plan_buckets(fc, arena.offsets, arena.sizes, arena.total, int(getattr(self, 'bucket_elems', BUCKET_ELEMS)))
+
     def close(self):
         """Release the captured hipGraphs now (they are re-captured if train_step is called again)."""
         for g in (self._segments or []):
@@ -145,6 +159,11 @@ class MoCoTrainer(_TrainerBase):
         self._static = None
         self._segments = None
         self._packers = None        # built after the first (eager) step, when every layer has its plan
+        self._buckets = None        # N > 1: [(closure index, lo, hi)] gradient buckets in completion order
+        self._tape = None
+        self._planned = False
+        self._plans = None          # N > 1: look-ahead ShuffleBN exchange plans (parallel.ExchangePlans)
+        self._reducer = par.BucketReducer(self.arena_q.grad, self.ctx)
         self.out = {}
 
     # -------------------------------------------------------------------------------- buffers
@@ -184,7 +203,9 @@ class MoCoTrainer(_TrainerBase):
         self._unpack('k')
         s['k_shuf'].copy_(kv.t)
 
-    def _phase_query(self):
+    def _phase_query(self, upto=0):
+        """Query encoder forward, InfoNCE, enqueue, dq and the backward pass down to tape index `upto` (0 = all of it;
+        N > 1 runs the rest in stages, one per gradient bucket: _phase_backward_stage)."""
         s = self._static
         b = s['images'].shape[0]
         self.optimizer.zero_grad()
@@ -199,9 +220,17 @@ class MoCoTrainer(_TrainerBase):
         qv.grad = ops.moco_logits_bwd(s['k'], mem, self.inv_T, logits=logits, lse=lse,
                                       gscale_host=1.0 / self.ctx.world, ov_rows=saved, ov_start_dev=self.ptr_dev)
         ops.queue_advance(self.ptr_dev, s['all_k'].shape[0], self.K)
-        tape.backward()
-        self._unpack('q')
         self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
+        tape.backward(upto)
+        self._tape = tape if upto > 0 else None
+        if upto == 0:
+            self._unpack('q')
+
+    def _phase_backward_stage(self, upto, last):
+        self._tape.backward(upto)
+        if last:
+            self._tape = None
+            self._unpack('q')
 
     def _phase_update(self):
         clip = None
@@ -229,7 +258,8 @@ class MoCoTrainer(_TrainerBase):
             raise RuntimeError('train_step needs fp32 clips already resident on %s' % self.device)
         s = self._ensure_static(images)
         b, W = images.shape[0], self.ctx.world
-        if shuffle_ids is None:
+        user_ids = shuffle_ids
+        if shuffle_ids is None and not self.ctx.active:
             shuffle_ids = par.shared_permutation(b * W, self.perm_seed, self.step_count)
         s['images'].copy_(images)
         self.optimizer._sync_tables()
@@ -239,17 +269,52 @@ class MoCoTrainer(_TrainerBase):
                 self._segments = [_Graphed(self._single_gpu_all, self.use_graph)]
             self._segments[0].run()
         else:
+            if self._plans is None or self._plans.b != b:
+                self._plans = par.ExchangePlans(b, self.ctx, self.perm_seed, self.device)
+            plan = self._plans.get(self.step_count, user_ids)
             if self._segments is None:
-                self._segments = [_Graphed(self._phase_key, self.use_graph), _Graphed(self._phase_query, self.use_graph),
-                                  _Graphed(self._phase_update, self.use_graph)]
+                # One graph segment per stage: key forward | query forward + InfoNCE + backward down to the first bucket
+                # boundary | one backward stage per further gradient bucket | update.  The all-reduce of a bucket is
+                # issued behind the segment that completes it and runs on RCCL's stream while the next stage computes
+                # (DDP's overlap, tools/train_video_contrast_dis.py:143,419, with a few 32 MB buckets).  Activations
+                # allocated while one segment is captured are read by the next: the segments share one graph memory pool.
+                pool = torch.cuda.graph_pool_handle() if self.use_graph else None
+                if self._buckets is None:
+                    self._buckets = [(0, 0, self.arena_q.total)]         # first step: un-staged; planned below
+                bk = self._buckets
+                last = len(bk) - 1
+                segs = [_Graphed(self._phase_key, self.use_graph, pool),
+                        _Graphed(lambda u=(0 if last == 0 else bk[0][0]): self._phase_query(u), self.use_graph, pool)]
+                for i in range(1, len(bk)):
+                    segs.append(_Graphed(lambda u=(0 if i == last else bk[i][0]), l=(i == last): self._phase_backward_stage(u, l),
+                                         self.use_graph, pool))
+                segs.append(_Graphed(self._phase_update, self.use_graph, pool))
+                self._segments = segs
             x2 = torch.chunk(s['images'], 2, dim=1)[1]
-            s['key_in'].copy_(par.shuffle_exchange(x2, shuffle_ids, self.ctx, ops.gather_rows))
+            s['key_in'].copy_(par.shuffle_exchange_planned(x2, plan, self.ctx, ops.gather_rows))
             self._segments[0].run()
             s['all_k'].copy_(par.gather_keys(s['k_shuf'], self.ctx))
-            s['k'].copy_(par.unshuffle_keys(s['all_k'], shuffle_ids, b, self.ctx, ops.gather_rows))
-            self._segments[1].run()
-            par.allreduce_sum_(self.arena_q.grad, self.ctx)
-            self._segments[2].run()
+            s['k'].copy_(ops.gather_rows(s['all_k'], plan['unshuffle_idx']))
+            bk = self._buckets
+            planning = len(bk) == 1 and not self._planned and self.arena_q.total > int(getattr(self, 'bucket_elems', BUCKET_ELEMS))
+            if planning:
+                self._planned = True
+                L.GRAD_LOG = []
+            for i, (_, lo, hi) in enumerate(bk):
+                self._segments[1 + i].run()
+                self._reducer.launch(lo, hi)
+            self._reducer.wait()
+            self._segments[-1].run()
+            if user_ids is None:
+                self._plans.prefetch(self.step_count + 1)        # host index work of the NEXT step, while this one runs
+            if planning:
+                # the first step ran un-staged with the gradient log on: cut the arena into buckets by the closure that
+                # completes each and rebuild the segments, so that every later step overlaps all-reduce and backward
+                log, L.GRAD_LOG = L.GRAD_LOG, None
+                self._buckets = self._buckets_from_log(self.arena_q, log)
+                for g in self._segments:
+                    g.release()
+                self._segments = None
         if self._packers is None:
             self._packers = dict(k=BatchedPacker(self.model_ema, (0,)), q=BatchedPacker(self.model, (0, 1)))
         self.contrast.index = (self.contrast.index + b * W) % self.K      # host mirror of ptr_dev

@@ -180,7 +180,8 @@ class ExchangePlans(object):
         ids = shared_permutation(b * ctx.world, self.seed, step) if shuffle_ids is None else shuffle_ids
         send_idx, send_counts, recv_counts, place_idx = exchange_plan(ids, b, ctx.rank, ctx.world)
         rev = torch.argsort(ids)[ctx.rank * b:(ctx.rank + 1) * b]
-        up = lambda t: (t.pin_memory() if t.numel() else t).to(self.device, non_blocking=True)
+        on_gpu = torch.device(self.device).type == 'cuda'
+        up = lambda t: (t.pin_memory() if (on_gpu and t.numel()) else t).to(self.device, non_blocking=True)
         return dict(ids=ids, send_idx=up(send_idx), place_idx=up(place_idx), unshuffle_idx=up(rev),
                     send_counts=send_counts, recv_counts=recv_counts)
 
