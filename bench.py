@@ -27,8 +27,10 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (spec)
 PEAK_HBM_GBPS = 8000.0            # HBM3E spec
-PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak; a bf16x3 / bf16x6 product costs 3 / 6 of them
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak; a bf16x3 / bf16x6 product costs 3 / 6 of them
 FWD_GFLOP_PER_VIEW = 16.953       # R(2+1)D-18 @16x112x112, conv+linear, 2*MAC
+# --math fp16 = BASELINE.json configs[4]: 3D-ResNet-50, 32-frame 224x224 clips, fp16 storage, 16 clips per GPU (global 128 on 8)
+FP16_DEFAULTS = dict(backbone='R3D50', frames=32, size=224, batch=16)
 
 
 def log(msg):
@@ -44,17 +46,19 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='clips per GPU')
-    ap.add_argument('--frames', type=int, default=16)
-    ap.add_argument('--size', type=int, default=112)
-    ap.add_argument('--backbone', default='R2P1D18')
+    ap.add_argument('--batch', type=int, default=0, help='clips per GPU (default 32; 16 with --math fp16)')
+    ap.add_argument('--frames', type=int, default=0, help='default 16 (32 with --math fp16)')
+    ap.add_argument('--size', type=int, default=0, help='default 112 (224 with --math fp16)')
+    ap.add_argument('--backbone', default='', help='default R2P1D18 (R3D50 with --math fp16)')
     ap.add_argument('--queue', type=int, default=0, help='0 = 4096 at N=1, 65536 at N>1 (BASELINE configs 2/3)')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--math', default='bf16x6', choices=['bf16x3', 'bf16x6', 'f32'],
+    ap.add_argument('--math', default='bf16x6', choices=['bf16x3', 'bf16x6', 'f32', 'fp16'],
                     help="conv arithmetic (include/gca_hip.h gca_set_conv_math): bf16x3 = fp32 operands split into bf16 "
                          "hi+lo, three bf16 MFMAs per product, fp32 accumulate (4.5e-6 rel. error vs fp32 MFMA, measured); "
                          "bf16x6 = hi+mid+lo, six products, fp32-grade; f32 = fp32 MFMA.  The other modes are timed too and "
-                         "reported beside the headline value")
+                         "reported beside the headline value.  fp16 = the fp16-STORAGE path on BASELINE configs[4] (3D-ResNet-50, 32x224x224, "
+                         "16 clips/GPU): feature maps and their gradients fp16 in HBM, v_mfma_f32_32x32x16_f16 with fp32 accumulate, "
+                         "fp32 master weights / statistics / head -- an HBM-bound workload, reported against the HBM roofline")
     ap.add_argument('--no-other-math', action='store_true', help='skip timing the other arithmetic modes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -62,7 +66,14 @@ def parse():
     ap.add_argument('--workload', default='moco', choices=['moco', 'simsiam'],
                     help="moco: BASELINE configs[1]/[2] (default, the headline line); simsiam: configs[3] -- "
                          "configs/visual_simsiam.yaml shape: S3D, 16x224x224, FEAT_DIM 1024, temporal-graph blocks on, 4 clips/GPU")
-    return ap.parse_args()
+    args = ap.parse_args()
+    base = FP16_DEFAULTS if args.math == 'fp16' else dict(backbone='R2P1D18', frames=16, size=112, batch=32)
+    if args.workload == 'simsiam':
+        base = dict(backbone='S3D', frames=16, size=224, batch=4)
+    for k, v in base.items():
+        if not getattr(args, k):
+            setattr(args, k, v)
+    return args
 
 
 def make_cfg(pkg, args, K):
@@ -117,6 +128,8 @@ def _sym(c, tail=0):
     vec, fast, math = c[1] == 256, (c[3] >> 8) & 3, (c[3] >> 12) & 3       # bit 10 only says the class COULD use float4 gathers
     if (c[3] >> 14) & 1:                                                    # LDS-halo kernel (conv3d_halo.hip)
         return 'conv_halo_kernel<%d,%d,%d>' % (c[0] // 32, c[1] // 128, math)
+    if (c[3] >> 15) & 1:                                                    # fp16-storage instantiation of the gather kernel
+        return 'conv_igemm_kernel<%d,%d,%d,%s,%d,true>' % (c[0] // 32, c[1], fast, 'true' if vec else 'false', math)
     tb = tail & 255
     if tail and c[2] == 1 and c[1] == 128 and (c[3] & 255) == 1 and fast in (1, 2) and 0 < tb <= 2 and tb * 32 < c[0]:
         return 'conv_igemm_2phase_kernel<%d,%d,%d,%d>' % (c[0] // 32, tb, fast, math)
@@ -128,7 +141,9 @@ DTYPE = {'f32': 'f32',
          'bf16x6': 'bf16x6 (fp32 tensors; conv products as 6 bf16 MFMAs on hi/mid/lo splits = fp32-grade, fp32 accumulate; '
                    'everything else fp32)',
          'bf16x3': 'bf16x3 (fp32 tensors; conv products as 3 bf16 MFMAs on hi/lo splits, 2^-17 relative, fp32 accumulate; '
-                   'everything else fp32)'}
+                   'everything else fp32)',
+         'fp16': 'f16 (feature maps and their gradients stored IEEE fp16; conv = v_mfma_f32_32x32x16_f16, fp32 accumulate; fp32 '
+                 'master weights, BatchNorm statistics, projection head, InfoNCE and optimizer)'}
 
 
 def kernel_timing(pkg, trainer, args):
@@ -155,20 +170,21 @@ def kernel_timing(pkg, trainer, args):
 
     dev = torch.device('cuda', torch.cuda.current_device())
     for i, (m, shp, xs) in enumerate(layers):
-        plan = ops.conv_plan(shp, m.out_channels, m.kernel_size, m.stride, m.padding, dev)
+        half = ops.ACT_F16[0] and m.__class__.__name__ != 'Lin'               # the head's Linear layers stay fp32
+        plan = ops.conv_plan(shp, m.out_channels, m.kernel_size, m.stride, m.padding, dev, act_f16=half)
         N, K, OD, OH, OW = plan.out_shape
         taps = m.kernel_size[0] * m.kernel_size[1] * m.kernel_size[2]
         flops = 2.0 * N * K * OD * OH * OW * shp[1] * taps
-        x = torch.randn(shp, device='cuda')
-        dy = torch.randn(plan.out_shape, device='cuda')
+        x = torch.randn(shp, device='cuda').to(plan.act_dtype)
+        dy = torch.randn(plan.out_shape, device='cuda').to(plan.act_dtype)
         w = m.weight.data
         wp0, wp1 = ops.conv_pack(plan, 0, w), ops.conv_pack(plan, 1, w)
         dw = torch.zeros_like(w)
-        dx = torch.empty(shp, device='cuda')
+        dx = torch.empty(shp, device='cuda', dtype=plan.act_dtype)
         t = ev_time_ms(lambda: ops.conv_fwd(plan, x, wp0, None, stats=True), 5, 1)
         t_f, t_d = t, None
         c0 = plan.cfg(0)
-        nbytes = 4.0 * (x.numel() + dy.numel() + w.numel())
+        nbytes = float(x.element_size()) * (x.numel() + dy.numel()) + 4.0 * w.numel()
         add(_sym(c0, plan.g.tune_fwd_tail), t, flops, 2, 1, nbytes)   # key + query forward
         if i > 0:                                                              # the stem never needs d(input)
             # (the head's first Linear does: its input is the encoder feature)
@@ -177,7 +193,7 @@ def kernel_timing(pkg, trainer, args):
             add(_sym(c1, plan.g.tune_dgrad_tail), t, flops, 1, max(1, c1[3] & 255), nbytes)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         cw = plan.cfg(2)
-        add('conv_wgrad_kernel<%dx%d>' % (cw[0], cw[1]), t, flops, 1, 1, nbytes)
+        add('conv_wgrad_kernel<%dx%d>%s' % (cw[0], cw[1], ' (fp16 storage)' if half else ''), t, flops, 1, 1, nbytes)
         if args.layer_table:
             log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%s/%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'
                 % (i, shp, K, m.kernel_size, m.stride, flops / 1e9, plan.cfg(0)[:3], plan.cfg(1)[:3] if i > 0 else '-',
@@ -192,7 +208,9 @@ def kernel_timing(pkg, trainer, args):
     common = dict(kernel=dom, traffic=pmc_traffic(dom), avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4),
                   launches_per_step=sym[dom][2], flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1),
                   algorithmic_bytes_per_launch_avg=round(sym[dom][3] / sym[dom][2], 1))
-    nprod = {0: 1, 1: 3, 2: 6}[_MATH[0]]
+    nprod = {0: 1, 1: 3, 2: 6, 3: 1}[_MATH[0]]
+    if _MATH[0] == 3 and ',true>' in dom:
+        nprod = 3                  # the fp16-storage gather kernels multiply as bf16x3 (an fp16 value is exactly hi + lo)
     if _MATH[0] == 0:
         roof = dict(bound='mfma', achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common)
@@ -207,8 +225,17 @@ def kernel_timing(pkg, trainer, args):
                         flop_per_byte=round(ai, 1), mfma_frac=round(ach / mfma_peak, 4), tflops=ach, **common)
         else:
             roof = dict(bound='mfma', achieved=ach, peak=round(mfma_peak, 1), unit='TFLOP/s', frac=round(ach / mfma_peak, 4),
-                        flop_per_byte=round(ai, 1), note='peak = dense bf16 MFMA 2500 TFLOP/s / %d products' % nprod, **common)
+                        flop_per_byte=round(ai, 1), note='peak = dense bf16/fp16 MFMA 2500 TFLOP/s / %d products' % nprod, **common)
     return roof, table
+
+
+def step_bytes_roofline(table, step_s):
+    """configs[4] is HBM-bound as a whole: the conv kernels' algorithmic bytes per step against the time of
+    the whole step -- a lower bound on the step's HBM efficiency (BatchNorm / pooling passes move bytes too and are not
+    counted here)."""
+    gb = sum(v['algorithmic_GBps'] * v['ms_per_step'] / 1e3 for v in table.values())
+    return dict(conv_algorithmic_GB_per_step=round(gb, 3), step_ms=round(step_s * 1e3, 3),
+                GBps=round(gb / step_s, 1), hbm_frac=round(gb / step_s / PEAK_HBM_GBPS, 4))
 
 
 def pmc_traffic(symbol):
@@ -290,7 +317,7 @@ def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
                          'CROSS.FEAT_DIM', 1024, 'SOLVER.BASE_LR', 0.06, 'SOLVER.LR_SCHEDULER', 'step',
                          'SOLVER.STEPS', [80, 120, 160], 'SOLVER.WARMUP_FACTOR', 0.01, 'SOLVER.WARMUP_ITERS', 10,
                          'SOLVER.MAX_EPOCHS', 200])
-    bsz, size = (args.batch if args.batch != 32 else 4), (args.size if args.size != 112 else 224)
+    bsz, size = args.batch, args.size
     tr = pkg.SimSiamTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
     torch.manual_seed(1 + rank)
     images = torch.randn(bsz, 6, 16, size, size, device=dev)
@@ -359,7 +386,7 @@ def cpu_baseline(args, K):
     cores = host_cores()
     torch.set_num_threads(cores)
     log('cpu baseline on %d host threads' % cores)
-    b = 4
+    b = 1 if args.math == 'fp16' else 4          # (one 32x224x224 R3D-50 clip pair is ~2 TFLOP of fp32 CPU work)
     torch.manual_seed(1)
     model, ema = owrap.create_visual_model(args.backbone, args.frames, 128, 'mlp', 'moco')
     ema.load_state_dict(model.state_dict())
@@ -373,7 +400,7 @@ def cpu_baseline(args, K):
     omoco.moco_train_step(model, ema, contrast, crit, opt, images, 0.999)      # warm-up
     log('cpu baseline warm-up iteration %.1fs' % (time.time() - t0))
     n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < 10 and n < 20):
+    while n < (1 if args.math == 'fp16' else 3) or (time.time() - t0 < 10 and n < 20):
         omoco.moco_train_step(model, ema, contrast, crit, opt, images, 0.999)
         n += 1
         if time.time() - t0 > 60:
@@ -429,7 +456,7 @@ def main():
         torch.cuda.synchronize()
 
     pkg.engine.ops.set_conv_math(args.math)
-    _MATH[0] = pkg.engine.ops.CONV_MATH[args.math]
+    _MATH[0] = 3 if args.math == 'fp16' else pkg.engine.ops.CONV_MATH[args.math]
     if args.workload == 'simsiam':
         return simsiam_main(args, pkg, dev, ctx, world, rank, barrier)
     K = args.queue or (4096 if world == 1 else 65536)
@@ -468,20 +495,20 @@ def main():
     global_batch = args.batch * world
     value = global_batch * args.steps / dt
     step_gflop = 4 * FWD_GFLOP_PER_VIEW * args.batch if (args.backbone, args.frames, args.size) == ('R2P1D18', 16, 112) else None
+    cfg_idx = 4 if args.math == 'fp16' else (1 if world == 1 else 2)
     res = {
         'metric': 'pretrain_clips_per_sec', 'value': round(value, 3), 'unit': 'clips/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': DTYPE[args.math], 'data': 'synthetic',
         'config': {'workload': 'MoCo pre-training iteration, %s, %d-frame %dx%d clips, %d clips/GPU (global %d), '
                                'queue K=%d, T=0.07, SGD+EMA (BASELINE.json configs[%d])'
-                               % (args.backbone, args.frames, args.size, args.size, args.batch, global_batch, K,
-                                  1 if world == 1 else 2),
+                               % (args.backbone, args.frames, args.size, args.size, args.batch, global_batch, K, cfg_idx),
                    'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, **({'rehearsal': 'gloo/host-staged on one GPU: NOT a measurement'} if rehearsal else {})},
         'views_per_sec': round(2 * value, 3), 'final_loss': round(loss, 5),
     }
     if step_gflop:
         res['step_tflops_algorithmic'] = round(step_gflop / 1e3 / (dt / args.steps), 3)
-    if world == 1:
+    if world == 1 and args.math != 'fp16':
         res['infonce_fwd'] = infonce_timing(pkg, 32)
         log('infonce timing done')
         res['infonce_fwd_ms'] = res['infonce_fwd']['K4096']['ms']
@@ -489,7 +516,7 @@ def main():
     if not args.no_kernel_timing:
         res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
         log('kernel timing done')
-    if world == 1 and not args.no_other_math:
+    if world == 1 and not args.no_other_math and args.math != 'fp16':
         # the same workload in the other arithmetic modes (own trainer, own tuned plans), timed the same way
         del tr
         import gc
@@ -516,6 +543,8 @@ def main():
         gc.collect()
         pkg.engine.ops.set_conv_math(args.math)
         _MATH[0] = pkg.engine.ops.CONV_MATH[args.math]
+    if args.math == 'fp16' and not args.no_kernel_timing:
+        res['roofline_step'] = step_bytes_roofline(res['kernels'], dt / args.steps)
     if world == 1:
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, K)

@@ -80,6 +80,14 @@ typedef struct {
                                                   positions inside one clip, coded bd | bh << 8 | bw << 16 (powers of two,
                                                   product 128 or 256); its input window is staged once per 16 channels in
                                                   LDS and every tap is formed from there.  0 with the flag clear */
+  int32_t act_f16;                             /* 1: the activation tensors of this convolution (x, y, dy, dx) are IEEE fp16 in
+                                                  HBM -- the fp16-storage path (the reference's apex-amp option,
+                                                  tools/train_video_contrast_dis.py:134-141,415-417).  Weights stay fp32
+                                                  masters (their packed copies are fp16 where the kernel multiplies in fp16),
+                                                  accumulation, BatchNorm statistics and dw are fp32.  The LDS-halo kernels
+                                                  multiply on v_mfma_f32_32x32x16_f16; the gather and weight-gradient kernels
+                                                  widen each fp16 operand to its exact bf16 hi + lo pair (three bf16 MFMAs).
+                                                  The conv arithmetic selector (gca_set_conv_math) does not apply. */
 } gca_conv_geom;
 
 /* Weight re-layout for the GEMM A operand (k-major, zero padded).  which: 0 = forward
@@ -113,7 +121,7 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
 /* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad), first non-empty class:
  * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask kind (0 none, 1: <=31 taps, 2: <=62)<<8 | float4-gather<<10 |
- *         arithmetic (0 f32, 1 bf16x3, 2 bf16x6)<<12}. */
+ *         arithmetic (0 f32, 1 bf16x3, 2 bf16x6, 3 fp16 MFMA)<<12 | LDS-halo kernel<<14 | fp16 storage<<15}. */
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
 /* Signature of the packed-weight layout that pass `which` (0 fwd, 1 dgrad) reads under the launch configuration in force:
  * one octal digit per problem class (0 = k-major fp32 rows of the gather kernels, 4 + arithmetic = the LDS-halo layout).
@@ -124,18 +132,19 @@ int64_t gca_conv_pack_layout(const gca_conv_geom* g, int which);
  * partial slabs live in `ws` (gca_conv_fwd_ws_bytes / gca_conv_dgrad_ws_bytes; 0 = not needed, ws may
  * then be NULL) and are summed in a fixed order (deterministic). */
 int64_t gca_conv_fwd_ws_bytes(const gca_conv_geom* g);
-int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, const int32_t* table,
-                 const float* bias, float* y, float* stat_sum, float* stat_sq, void* ws, void* stream);
+/* x / y / dy / dx: fp32, or IEEE fp16 when g->act_f16 = 1 (weights, bias, statistics and slabs are fp32 either way). */
+int gca_conv_fwd(const gca_conv_geom* g, const void* x, const float* wpack, const int32_t* table,
+                 const float* bias, void* y, float* stat_sum, float* stat_sq, void* ws, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  `wpack`/`table` from which=1.  accumulate != 0 adds into dx. */
 int64_t gca_conv_dgrad_ws_bytes(const gca_conv_geom* g);
-int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, const int32_t* table,
-                   float* dx, int accumulate, void* ws, void* stream);
+int gca_conv_dgrad(const gca_conv_geom* g, const void* dy, const float* wpack, const int32_t* table,
+                   void* dx, int accumulate, void* ws, void* stream);
 
 /* dw (+)= sum_{n,o} dy[n,k,o] * x[n,c,o*s-p+tap].  `table` from which=2.  Split-K partial slabs go
  * to `ws` (gca_conv_wgrad_ws_bytes) and are reduced deterministically. */
 int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g);
-int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
+int gca_conv_wgrad(const gca_conv_geom* g, const void* x, const void* dy, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream);
 /* Launch shape the wgrad kernel will use for g: out4 = {tile rows (output channels), tile columns (C*taps),
  * split-K factor, shape index | float4 dY loads<<8 | tap-mask kind<<9 | float4 X gathers<<11 | arithmetic<<12}. */
@@ -149,12 +158,14 @@ int gca_bias_grad(const float* dy, int64_t N, int64_t K, int64_t SP, float* db, 
  * residual add.  Replaces nn.BatchNorm3d/1d + ReLU + `out += residual`:
  * resnet2p1d.py:49-57,66-85; s3d_1.py:41-47,54-68; project_head.py:39-50,64-68.
  * Data layout (N, C, SP) with SP = D*H*W (1 for BatchNorm1d).
+ * act_f16 = 1: the activation tensors (x, residual, z, dz_in, dx, dres -- the `void*` arguments) are IEEE fp16
+ * (the fp16-storage path of BASELINE configs[4]); statistics, parameters and all arithmetic stay fp32/fp64.
  * ------------------------------------------------------------------------------------- */
 /* From conv-epilogue partials [C][P] (or computed by gca_bn_stats): mean/invstd (saved for
  * backward), running stats update (momentum, unbiased var), and the folded affine
  * scale = gamma*invstd, shift = beta - mean*scale.  count = N*SP. */
-int gca_bn_stats(const float* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
-                 int64_t* parts_out, void* stream);          /* P is fixed: gca_bn_stats_parts() */
+int gca_bn_stats(const void* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
+                 int64_t* parts_out, int act_f16, void* stream);          /* P is fixed: gca_bn_stats_parts() */
 int64_t gca_bn_stats_parts(int64_t N, int64_t C, int64_t SP);
 int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
                     const float* gamma, const float* beta, float eps, float momentum,
@@ -166,27 +177,27 @@ int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int
                      const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      float* save_mean, float* save_invstd, float* scale, float* shift,
-                     const float* x, const float* residual, int relu, int64_t N, int64_t SP, float* z,
-                     int64_t z_batch_stride, void* stream);
+                     const void* x, const void* residual, int relu, int64_t N, int64_t SP, void* z,
+                     int64_t z_batch_stride, int act_f16, void* stream);
 /* Eval-mode fold (running stats): scale/shift only. */
 int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int64_t C, float* scale, float* shift, void* stream);
 /* z = [relu]( x*scale[c] + shift[c] [+ residual] ).  z_batch_stride (elements; 0 = C*SP) lets z be a
  * channel slice of a wider (N, Ctot, SP) buffer: the Inception branches write straight into their
  * slice of the concat output (s3d_1.py:96 torch.cat) instead of being copied there. */
-int gca_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
-                 int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream);
+int gca_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,
+                 int relu, int64_t N, int64_t C, int64_t SP, void* z, int64_t z_batch_stride, int act_f16, void* stream);
 /* Backward of the fused op.  dz_in = gradient wrt z; x = saved conv output.  relu: 0 none; 1 mask from the saved
  * output z (z > 0); 2 mask recomputed from x with the forward's own scale/shift (x*scale+shift > 0) -- z may be
  * NULL and is not read: one tensor less to stream, valid when no residual was added before the ReLU.
  * Writes dx (gradient wrt x), accumulates dgamma/dbeta (+=) and, if dres != NULL, writes (dres_accumulate=0) or
  * adds (=1) the gradient wrt the residual input.  ws: gca_bn_bwd_ws_bytes(). */
 int64_t gca_bn_bwd_ws_bytes(int64_t N, int64_t C, int64_t SP);
-int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* gamma,
+int gca_bn_bwd(const void* dz_in, const void* z, const void* x, const float* gamma,
                const float* save_mean, const float* save_invstd, int relu,
-               int64_t N, int64_t C, int64_t SP, float* dx, float* dgamma, float* dbeta,
-               float* dres, int dres_accumulate, int64_t z_batch_stride /* of dz_in and z */,
-               const float* scale, const float* shift, void* ws, void* stream);
+               int64_t N, int64_t C, int64_t SP, void* dx, float* dgamma, float* dbeta,
+               void* dres, int dres_accumulate, int64_t z_batch_stride /* of dz_in and z */,
+               const float* scale, const float* shift, void* ws, int act_f16, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Pooling.  MaxPool3d: resnet2p1d.py:178, s3d_1.py:10,13,16,22,87, temporal_graph.py:100
@@ -201,15 +212,16 @@ typedef struct {
 } gca_pool_geom;
 /* scale/shift (both or neither): pool relu(x*scale[c] + shift[c]) instead of x -- the BatchNorm+ReLU in front of
  * the pool (resnet2p1d.py:252-255 conv1_t -> bn1_t -> relu -> maxpool) evaluated on the fly. */
-int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, const float* scale,
-                      const float* shift, void* stream);
-int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* argmax, float* dx,
-                      int accumulate, void* stream);
+int gca_maxpool3d_fwd(const gca_pool_geom* g, const void* x, void* y, int32_t* argmax, const float* scale,
+                      const float* shift, int act_f16, void* stream);
+int gca_maxpool3d_bwd(const gca_pool_geom* g, const void* dy, const int32_t* argmax, void* dx,
+                      int accumulate, int act_f16, void* stream);
 /* y[n,c] = sum_{d,h,w} wt[d] * x[n,c,d,h,w] * norm   (wt == NULL -> all ones) */
-int gca_wavgpool_fwd(const float* x, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
-                     float* y, void* stream);
+/* x_f16: the feature map (x, dx) is stored fp16; the pooled features y / dy are fp32 either way (the head is fp32). */
+int gca_wavgpool_fwd(const void* x, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
+                     float* y, int x_f16, void* stream);
 int gca_wavgpool_bwd(const float* dy, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
-                     float* dx, void* stream);
+                     void* dx, int x_f16, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Head pieces.  ReLU between the two Linear layers (project_head.py:24-27) and row L2
@@ -312,6 +324,10 @@ int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out2
 int gca_fill(float* p, int64_t n, float v, void* stream);
 int gca_axpy(float* y, const float* x, int64_t n, float a, void* stream);          /* y += a*x */
 int gca_scale(float* y, int64_t n, float a, void* stream);
+/* fp16-storage path: y += a*x on fp16 tensors (fp32 arithmetic, one rounding), and the fp32 -> fp16 cast of the input clips */
+int gca_axpy_f16(void* y, const void* x, int64_t n, float a, void* stream);
+/* rows x row_elems (row_elems % 4 == 0), source rows src_row_stride elements apart (a channel slice of a clip batch) */
+int gca_cast_f16(const float* x, int64_t rows, int64_t row_elems, int64_t src_row_stride, void* y, void* stream);
 /* dst[r,:] = src[idx[r]*src_row_stride : +row_elems]; rows <= 65535.  src rows may be strided (the key view of a
  * (b,6,T,H,W) batch is gathered in place for the ShuffleBN exchange, tools/...dis.py:404,213-217). */
 int gca_gather_rows(const float* src, const int64_t* idx, int64_t rows, int64_t row_elems, int64_t src_row_stride,

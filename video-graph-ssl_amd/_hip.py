@@ -32,7 +32,7 @@ class ConvGeom(C.Structure):
                [(n, c_i32) for n in ('tune_fwd_bm', 'tune_fwd_splits', 'tune_dgrad_bm', 'tune_dgrad_splits',
                                      'tune_wgrad_splits', 'tune_wgrad_tile', 'tune_fwd_tail', 'tune_dgrad_tail',
                                      'tune_fwd_math', 'tune_dgrad_math', 'tune_wgrad_math', 'tune_fwd_box',
-                                     'tune_dgrad_box')]
+                                     'tune_dgrad_box', 'act_f16')]
 
 
 class PoolGeom(C.Structure):
@@ -61,21 +61,21 @@ SIGNATURES = {
     'gca_conv_wgrad_ws_bytes': (c_i64, [_GP]),
     'gca_conv_wgrad': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     'gca_bias_grad': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),
-    'gca_bn_stats': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    'gca_bn_stats': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'gca_bn_stats_parts': (c_i64, [c_i64, c_i64, c_i64]),
     'gca_bn_finalize': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
                                 c_vp, c_vp, c_vp, c_vp, c_vp]),
     'gca_bn_train_fwd': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_f64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp,
-                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_vp]),
+                                 c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'gca_bn_fold_eval': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_i64, c_vp, c_vp, c_vp]),
-    'gca_bn_apply': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
+    'gca_bn_apply': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_i32, c_vp]),
     'gca_bn_bwd_ws_bytes': (c_i64, [c_i64, c_i64, c_i64]),
     'gca_bn_bwd': (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp,
-                           c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
-    'gca_maxpool3d_fwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    'gca_maxpool3d_bwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_i32, c_vp]),
-    'gca_wavgpool_fwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_vp]),
-    'gca_wavgpool_bwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_vp]),
+                           c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'gca_maxpool3d_fwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    'gca_maxpool3d_bwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    'gca_wavgpool_fwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),
+    'gca_wavgpool_bwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),
     'gca_relu_fwd': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
     'gca_relu_bwd': (c_i32, [c_vp, c_vp, c_i64, c_vp, c_vp]),
     'gca_l2norm_fwd': (c_i32, [c_vp, c_i64, c_i64, c_f32, c_vp, c_vp, c_vp]),
@@ -104,6 +104,8 @@ SIGNATURES = {
     'gca_fill': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
     'gca_axpy': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     'gca_scale': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
+    'gca_axpy_f16': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
+    'gca_cast_f16': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     'gca_conv_pack_jobs_host': (c_i64, [_GP, c_i32, c_vp, c_vp, c_vp]),
     'gca_conv_pack_jobs_finalize_host': (c_i64, [c_vp, c_i64]),
     'gca_conv_pack_batched': (c_i32, [c_vp, c_i64, c_i64, c_vp]),
@@ -117,13 +119,29 @@ for _name, (_res, _args) in SIGNATURES.items():
 PACK_JOB_BYTES = 128      # GCA_PACK_JOB_BYTES
 
 
-def ptr(t):
-    """Device pointer of a (contiguous, fp32/int) CUDA tensor, or NULL."""
+def ptr(t, half_ok=False):
+    """Device pointer of a (contiguous, fp32/int) CUDA tensor, or NULL.  fp16 tensors are only accepted where the kernel
+    behind the call takes the activation storage type as an argument (half_ok, see aptr)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError('gca HIP ops need tensors on the GPU (got %s); there is no CPU fallback' % t.device)
+    if t.dtype is not torch.float32 and not (half_ok and t.dtype is torch.float16) and t.is_floating_point():
+        raise TypeError('this gca HIP op has no %s kernel' % t.dtype)
     return t.data_ptr()
+
+
+def aptr(t):
+    """Pointer of an activation tensor: fp32, or fp16 on the fp16-storage path."""
+    return ptr(t, True)
+
+
+def is_half(*ts):
+    """1 when the activation tensors are fp16 (all of them must then be), else 0."""
+    kinds = {t.dtype for t in ts if t is not None}
+    if len(kinds) > 1:
+        raise TypeError('mixed activation storage types: %s' % sorted(map(str, kinds)))
+    return int(kinds == {torch.float16})
 
 
 def stream():

@@ -20,12 +20,13 @@ __host__ __device__ inline long long stats_parts(long long N, long long C, long 
 // grid (P, C): block (part, c) reduces a contiguous slice of channel c's N*SP elements.
 // `f(i_global)` style is avoided: we walk (n, sp) so reads stay contiguous inside a plane.
 // VEC = 4 (SP % 4 == 0, 16-byte aligned operands): float4 loads, two of them in flight per tensor.
-template <int MODE, int VEC>   // MODE 0: sum x, x^2     1: sum dz, dz*xhat (backward)
+template <typename T, int MODE, int VEC>   // MODE 0: sum x, x^2     1: sum dz, dz*xhat (backward)
 __global__ __launch_bounds__(256) void bn_reduce_kernel(
-    const float* __restrict__ a, const float* __restrict__ z, const float* __restrict__ x,
+    const T* __restrict__ a, const T* __restrict__ z, const T* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
     long long N, long long C, long long SP, long long zs, int P, float* __restrict__ out0,
     float* __restrict__ out1, const float* __restrict__ scale, const float* __restrict__ shift) {
+  typedef gca_act<T> A_;
   __shared__ double sh[4];
   const int c = blockIdx.y, part = blockIdx.x;
   // relu == 2: the ReLU mask is recomputed from the conv output exactly as bn_apply computed it (x*scale+shift > 0)
@@ -65,14 +66,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
       const long long zi = n * zs + c * SP + sp, zi2 = n2 * zs + c * SP + sp2;
       float4 a0, a1, z0 = zero4, z1 = zero4, x0 = zero4, x1 = zero4;
       if (MODE == 0) {
-        a0 = *reinterpret_cast<const float4*>(a + idx);
-        a1 = two ? *reinterpret_cast<const float4*>(a + idx2) : zero4;
+        a0 = A_::ld4(a + idx);
+        a1 = two ? A_::ld4(a + idx2) : zero4;
       } else {
-        a0 = *reinterpret_cast<const float4*>(a + zi);
-        a1 = two ? *reinterpret_cast<const float4*>(a + zi2) : zero4;
-        if (relu == 1) { z0 = *reinterpret_cast<const float4*>(z + zi); if (two) z1 = *reinterpret_cast<const float4*>(z + zi2); }
-        x0 = *reinterpret_cast<const float4*>(x + idx);
-        x1 = two ? *reinterpret_cast<const float4*>(x + idx2) : make_float4(mu, mu, mu, mu);
+        a0 = A_::ld4(a + zi);
+        a1 = two ? A_::ld4(a + zi2) : zero4;
+        if (relu == 1) { z0 = A_::ld4(z + zi); if (two) z1 = A_::ld4(z + zi2); }
+        x0 = A_::ld4(x + idx);
+        x1 = two ? A_::ld4(x + idx2) : make_float4(mu, mu, mu, mu);
       }
       accum(a0, z0, x0);
       if (two) accum(a1, z1, x1);
@@ -86,13 +87,13 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(
     else { n = i / SP; sp = i - n * SP; }
     const long long idx = (n * C + c) * SP + sp;
     if (MODE == 0) {
-      const double v = (double)a[idx];
+      const double v = (double)A_::ld(a + idx);
       s0 += v; s1 += v * v;
     } else {
       const long long zidx = n * zs + c * SP + sp;       // dz / z may be channel slices of a concat buffer
-      float dz = a[zidx];
-      const float xv = x[idx];
-      if (relu == 1 && !(z[zidx] > 0.f)) dz = 0.f;
+      float dz = A_::ld(a + zidx);
+      const float xv = A_::ld(x + idx);
+      if (relu == 1 && !(A_::ld(z + zidx) > 0.f)) dz = 0.f;
       if (relu == 2 && !(xv * rsc + rsf > 0.f)) dz = 0.f;
       s0 += (double)dz; s1 += (double)dz * (double)((xv - mu) * is);
     }
@@ -148,11 +149,12 @@ __global__ void bn_fold_eval_kernel(const float* gamma, const float* beta, const
 }
 
 // z = [relu](x*scale[c] + shift[c] [+ res]);  VEC = 4 when SP % 4 == 0 (a float4 never straddles a plane)
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
-    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* __restrict__ res, int relu, long long total, long long C, long long SP, long long zs,
-    float* __restrict__ z) {
+    const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+    const T* __restrict__ res, int relu, long long total, long long C, long long SP, long long zs,
+    T* __restrict__ z) {
+  typedef gca_act<T> A_;
   const long long stride = (long long)gridDim.x * 256 * VEC;
   const bool small = total < (1LL << 31);           // 32-bit index math (the usual case)
   const long long zskip = zs - C * SP;              // extra elements between samples of z (concat slice)
@@ -163,16 +165,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     const long long zi = i + n * zskip;
     const float sc = scale[c], sf = shift[c];
     if (VEC == 4) {
-      float4 v = *reinterpret_cast<const float4*>(x + i);
+      float4 v = A_::ld4(x + i);
       v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
-      if (res) { const float4 r = *reinterpret_cast<const float4*>(res + i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (res) { const float4 r = A_::ld4(res + i); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      *reinterpret_cast<float4*>(z + zi) = v;
+      A_::st4(z + zi, v);
     } else {
-      float v = x[i] * sc + sf;
-      if (res) v += res[i];
+      float v = A_::ld(x + i) * sc + sf;
+      if (res) v += A_::ld(res + i);
       if (relu) v = fmaxf(v, 0.f);
-      z[zi] = v;
+      A_::st(z + zi, v);
     }
   }
 }
@@ -198,12 +200,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
   }
 }
 
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ dzin, const float* __restrict__ z, const float* __restrict__ x,
+    const T* __restrict__ dzin, const T* __restrict__ z, const T* __restrict__ x,
     const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-    int relu, long long total, long long C, long long SP, long long zs, float* __restrict__ dx,
-    float* __restrict__ dres, int dres_acc, const float* __restrict__ scale, const float* __restrict__ shift) {
+    int relu, long long total, long long C, long long SP, long long zs, T* __restrict__ dx,
+    T* __restrict__ dres, int dres_acc, const float* __restrict__ scale, const float* __restrict__ shift) {
+  typedef gca_act<T> A_;
   const long long stride = (long long)gridDim.x * 256 * VEC;
   const bool small = total < (1LL << 31);           // 32-bit index math (the usual case)
   const long long zskip = zs - C * SP;
@@ -215,12 +218,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float A = coef[c], B = coef[C + c], Cc = coef[2 * C + c], mu = mean[c], is = invstd[c];
     const float rsc = relu == 2 ? scale[c] : 0.f, rsf = relu == 2 ? shift[c] : 0.f;
     if (VEC == 4) {
-      float4 d = *reinterpret_cast<const float4*>(dzin + zi);
+      float4 d = A_::ld4(dzin + zi);
       if (relu == 1) {
-        const float4 zz = *reinterpret_cast<const float4*>(z + zi);
+        const float4 zz = A_::ld4(z + zi);
         if (!(zz.x > 0.f)) d.x = 0.f; if (!(zz.y > 0.f)) d.y = 0.f; if (!(zz.z > 0.f)) d.z = 0.f; if (!(zz.w > 0.f)) d.w = 0.f;
       }
-      const float4 xv = *reinterpret_cast<const float4*>(x + i);
+      const float4 xv = A_::ld4(x + i);
       if (relu == 2) {
         if (!(xv.x * rsc + rsf > 0.f)) d.x = 0.f; if (!(xv.y * rsc + rsf > 0.f)) d.y = 0.f;
         if (!(xv.z * rsc + rsf > 0.f)) d.z = 0.f; if (!(xv.w * rsc + rsf > 0.f)) d.w = 0.f;
@@ -230,18 +233,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
       o.y = A * (d.y - B - (xv.y - mu) * is * Cc);
       o.z = A * (d.z - B - (xv.z - mu) * is * Cc);
       o.w = A * (d.w - B - (xv.w - mu) * is * Cc);
-      *reinterpret_cast<float4*>(dx + i) = o;
+      A_::st4(dx + i, o);
       if (dres) {
-        if (dres_acc) { const float4 r = *reinterpret_cast<const float4*>(dres + i); d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
-        *reinterpret_cast<float4*>(dres + i) = d;
+        if (dres_acc) { const float4 r = A_::ld4(dres + i); d.x += r.x; d.y += r.y; d.z += r.z; d.w += r.w; }
+        A_::st4(dres + i, d);
       }
     } else {
-      float d = dzin[zi];
-      const float xv = x[i];
-      if (relu == 1 && !(z[zi] > 0.f)) d = 0.f;
+      float d = A_::ld(dzin + zi);
+      const float xv = A_::ld(x + i);
+      if (relu == 1 && !(A_::ld(z + zi) > 0.f)) d = 0.f;
       if (relu == 2 && !(xv * rsc + rsf > 0.f)) d = 0.f;
-      dx[i] = A * (d - B - (xv - mu) * is * Cc);
-      if (dres) dres[i] = dres_acc ? dres[i] + d : d;
+      A_::st(dx + i, A * (d - B - (xv - mu) * is * Cc));
+      if (dres) A_::st(dres + i, dres_acc ? A_::ld(dres + i) + d : d);
     }
   }
 }
@@ -249,14 +252,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // Training-mode BatchNorm forward of one channel in ONE workgroup (small N*SP): fold the conv epilogue's partial sums
 // (fp64, as bn_finalize_kernel), update the running statistics, then normalise the channel (+residual, +ReLU, concat
 // slice) -- finalize and apply in one launch.
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
     const float* __restrict__ psum, const float* __restrict__ psq, long long P, double count,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean, float* __restrict__ sinvstd,
     float* __restrict__ scale, float* __restrict__ shift, long long* __restrict__ nbt,
-    const float* __restrict__ x, const float* __restrict__ res, int relu, int N, int C, int SP, long long zs,
-    float* __restrict__ z) {
+    const T* __restrict__ x, const T* __restrict__ res, int relu, int N, int C, int SP, long long zs,
+    T* __restrict__ z) {
+  typedef gca_act<T> A_;
   __shared__ double sh[4];
   __shared__ float ab[2];
   const int c = blockIdx.x;
@@ -290,16 +294,16 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
     const int n = i / per, sp = (i - n * per) * VEC;
     const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
     if (VEC == 4) {
-      float4 v = *reinterpret_cast<const float4*>(x + xi);
+      float4 v = A_::ld4(x + xi);
       v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
-      if (res) { const float4 r = *reinterpret_cast<const float4*>(res + xi); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (res) { const float4 r = A_::ld4(res + xi); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      *reinterpret_cast<float4*>(z + zi) = v;
+      A_::st4(z + zi, v);
     } else {
-      float v = x[xi] * sc + sf;
-      if (res) v += res[xi];
+      float v = A_::ld(x + xi) * sc + sf;
+      if (res) v += A_::ld(res + xi);
       if (relu) v = fmaxf(v, 0.f);
-      z[zi] = v;
+      A_::st(z + zi, v);
     }
   }
 }
@@ -308,12 +312,13 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
 // a small batch): pass 1 reduces (sum dz, sum dz*xhat) in fp64, the block derives the coefficients and accumulates
 // dgamma / dbeta, pass 2 re-reads the (L2-resident) operands and writes dx (+ the residual gradient).  Replaces
 // three launches (reduce, finalize, apply) that cost more in launch latency than in work at these sizes.
-template <int VEC>
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
-    const float* __restrict__ dzin, const float* __restrict__ z, const float* __restrict__ x,
+    const T* __restrict__ dzin, const T* __restrict__ z, const T* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-    int N, int C, int SP, long long zs, float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dres, int dres_acc, const float* __restrict__ scale, const float* __restrict__ shift) {
+    int N, int C, int SP, long long zs, T* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    T* __restrict__ dres, int dres_acc, const float* __restrict__ scale, const float* __restrict__ shift) {
+  typedef gca_act<T> A_;
   __shared__ double sh[4];
   const int c = blockIdx.x;
   const float mu = mean[c], is = invstd[c];
@@ -325,11 +330,11 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
     float dv[VEC], xv[VEC], zv[VEC];
     if (VEC == 4) {
-      const float4 d4 = *reinterpret_cast<const float4*>(dzin + zi), x4 = *reinterpret_cast<const float4*>(x + xi);
+      const float4 d4 = A_::ld4(dzin + zi), x4 = A_::ld4(x + xi);
       dv[0] = d4.x; dv[VEC > 1 ? 1 : 0] = d4.y; dv[VEC > 2 ? 2 : 0] = d4.z; dv[VEC > 3 ? 3 : 0] = d4.w;
       xv[0] = x4.x; xv[VEC > 1 ? 1 : 0] = x4.y; xv[VEC > 2 ? 2 : 0] = x4.z; xv[VEC > 3 ? 3 : 0] = x4.w;
-      if (relu == 1) { const float4 z4 = *reinterpret_cast<const float4*>(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
-    } else { dv[0] = dzin[zi]; xv[0] = x[xi]; if (relu == 1) zv[0] = z[zi]; }
+      if (relu == 1) { const float4 z4 = A_::ld4(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
+    } else { dv[0] = A_::ld(dzin + zi); xv[0] = A_::ld(x + xi); if (relu == 1) zv[0] = A_::ld(z + zi); }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float d = dv[e];
@@ -351,11 +356,11 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
     float dv[VEC], xv[VEC], zv[VEC], ov[VEC];
     if (VEC == 4) {
-      const float4 d4 = *reinterpret_cast<const float4*>(dzin + zi), x4 = *reinterpret_cast<const float4*>(x + xi);
+      const float4 d4 = A_::ld4(dzin + zi), x4 = A_::ld4(x + xi);
       dv[0] = d4.x; dv[VEC > 1 ? 1 : 0] = d4.y; dv[VEC > 2 ? 2 : 0] = d4.z; dv[VEC > 3 ? 3 : 0] = d4.w;
       xv[0] = x4.x; xv[VEC > 1 ? 1 : 0] = x4.y; xv[VEC > 2 ? 2 : 0] = x4.z; xv[VEC > 3 ? 3 : 0] = x4.w;
-      if (relu == 1) { const float4 z4 = *reinterpret_cast<const float4*>(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
-    } else { dv[0] = dzin[zi]; xv[0] = x[xi]; if (relu == 1) zv[0] = z[zi]; }
+      if (relu == 1) { const float4 z4 = A_::ld4(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
+    } else { dv[0] = A_::ld(dzin + zi); xv[0] = A_::ld(x + xi); if (relu == 1) zv[0] = A_::ld(z + zi); }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       if (relu == 1 && !(zv[e] > 0.f)) dv[e] = 0.f;
@@ -363,15 +368,15 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
       ov[e] = A * (dv[e] - B - (xv[e] - mu) * is * Cc);
     }
     if (VEC == 4) {
-      *reinterpret_cast<float4*>(dx + xi) = make_float4(ov[0], ov[VEC > 1 ? 1 : 0], ov[VEC > 2 ? 2 : 0], ov[VEC > 3 ? 3 : 0]);
+      A_::st4(dx + xi, make_float4(ov[0], ov[VEC > 1 ? 1 : 0], ov[VEC > 2 ? 2 : 0], ov[VEC > 3 ? 3 : 0]));
       if (dres) {
         float4 r = make_float4(dv[0], dv[VEC > 1 ? 1 : 0], dv[VEC > 2 ? 2 : 0], dv[VEC > 3 ? 3 : 0]);
-        if (dres_acc) { const float4 o = *reinterpret_cast<const float4*>(dres + xi); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-        *reinterpret_cast<float4*>(dres + xi) = r;
+        if (dres_acc) { const float4 o = A_::ld4(dres + xi); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
+        A_::st4(dres + xi, r);
       }
     } else {
-      dx[xi] = ov[0];
-      if (dres) dres[xi] = dres_acc ? dres[xi] + dv[0] : dv[0];
+      A_::st(dx + xi, ov[0]);
+      if (dres) A_::st(dres + xi, dres_acc ? A_::ld(dres + xi) + dv[0] : dv[0]);
     }
   }
 }
@@ -385,25 +390,126 @@ inline unsigned ew_grid(long long total, int vec) {
 
 }  // namespace
 
-extern "C" {
+extern "C" int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                               const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                               float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
 
-int64_t gca_bn_stats_parts(int64_t N, int64_t C, int64_t SP) { return stats_parts(N, C, SP); }
-
-int gca_bn_stats(const float* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
+template <typename T>
+static int bn_stats_t(const T* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
                  int64_t* parts_out, void* stream) {
   if (!x || !stat_sum || !stat_sq || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
   const int P = (int)stats_parts(N, C, SP);
   if (parts_out) *parts_out = P;
   if (SP % 4 == 0 && ((uintptr_t)x % 16) == 0)
-    hipLaunchKernelGGL((bn_reduce_kernel<0, 4>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
-                       nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 0, 4>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
                        stat_sum, stat_sq, nullptr, nullptr);
   else
-    hipLaunchKernelGGL((bn_reduce_kernel<0, 1>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, nullptr,
-                       nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 0, 1>), dim3(P, (unsigned)C), dim3(256), 0, (hipStream_t)stream, x, (const T*)nullptr,
+                       (const T*)nullptr, nullptr, nullptr, 0, (long long)N, (long long)C, (long long)SP, (long long)(C * SP), P,
                        stat_sum, stat_sq, nullptr, nullptr);
   return gca_launch_status();
 }
+
+template <typename T>
+static int bn_apply_t(const T* x, const float* scale, const float* shift, const T* residual,
+                 int relu, int64_t N, int64_t C, int64_t SP, T* z, int64_t z_batch_stride, void* stream) {
+  if (!x || !scale || !shift || !z || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+  const long long total = (long long)N * C * SP;
+  const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)x | (uintptr_t)z | (uintptr_t)residual) % 16 == 0);
+  if (v4)
+    hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(ew_grid(total, 4)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, residual, relu, total, (long long)C, (long long)SP, zs, z);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<T, 1>), dim3(ew_grid(total, 1)), dim3(256), 0, (hipStream_t)stream, x, scale,
+                       shift, residual, relu, total, (long long)C, (long long)SP, zs, z);
+  return gca_launch_status();
+}
+
+template <typename T>
+static int bn_train_fwd_t(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* save_mean, float* save_invstd, float* scale, float* shift,
+                     const T* x, const T* residual, int relu, int64_t N, int64_t SP, T* z,
+                     int64_t z_batch_stride, void* stream) {
+  if (!x || !z || N <= 0 || SP <= 0 || (double)N * (double)SP != count) return GCA_EINVAL;
+  if (!stat_sum || !stat_sq || P <= 0 || C <= 0 || !scale || !shift) return GCA_EINVAL;
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  if (N * SP <= BN_SMALL_ELEMS && N * C * SP < (1LL << 31)) {
+    const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+    const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)x | (uintptr_t)z | (uintptr_t)residual) % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (v4)
+      hipLaunchKernelGGL((bn_fwd_small_kernel<T, 4>), dim3((unsigned)C), dim3(256), 0, st, stat_sum, stat_sq, (long long)P, count,
+                         gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                         (long long*)num_batches_tracked, x, residual, relu, (int)N, (int)C, (int)SP, zs, z);
+    else
+      hipLaunchKernelGGL((bn_fwd_small_kernel<T, 1>), dim3((unsigned)C), dim3(256), 0, st, stat_sum, stat_sq, (long long)P, count,
+                         gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                         (long long*)num_batches_tracked, x, residual, relu, (int)N, (int)C, (int)SP, zs, z);
+    return gca_launch_status();
+  }
+  int rc = gca_bn_finalize(stat_sum, stat_sq, P, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                           num_batches_tracked, save_mean, save_invstd, scale, shift, stream);
+  if (rc) return rc;
+  return bn_apply_t<T>(x, scale, shift, residual, relu, N, C, SP, z, z_batch_stride, stream);
+}
+
+template <typename T>
+static int bn_bwd_t(const T* dz_in, const T* z, const T* x, const float* gamma,
+               const float* save_mean, const float* save_invstd, int relu,
+               int64_t N, int64_t C, int64_t SP, T* dx, float* dgamma, float* dbeta,
+               T* dres, int dres_accumulate, int64_t z_batch_stride, const float* scale, const float* shift,
+               void* ws, void* stream) {
+  if (!dz_in || !x || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
+  if (relu < 0 || relu > 2 || (relu == 1 && !z) || (relu == 2 && (!scale || !shift))) return GCA_EINVAL;
+  if (relu != 1) z = dz_in;                 // never dereferenced; keeps the alignment test below meaningful
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+  hipStream_t st = (hipStream_t)stream;
+  if (N * SP <= BN_SMALL_ELEMS && N * C * SP < (1LL << 31)) {
+    const bool s4 = (SP % 4 == 0) && (zs % 4 == 0) &&
+                    (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
+    if (s4)
+      hipLaunchKernelGGL((bn_bwd_small_kernel<T, 4>), dim3((unsigned)C), dim3(256), 0, st, dz_in, z, x, gamma, save_mean, save_invstd,
+                         relu, (int)N, (int)C, (int)SP, zs, dx, dgamma, dbeta, dres, dres_accumulate, scale, shift);
+    else
+      hipLaunchKernelGGL((bn_bwd_small_kernel<T, 1>), dim3((unsigned)C), dim3(256), 0, st, dz_in, z, x, gamma, save_mean, save_invstd,
+                         relu, (int)N, (int)C, (int)SP, zs, dx, dgamma, dbeta, dres, dres_accumulate, scale, shift);
+    return gca_launch_status();
+  }
+  const int P = (int)stats_parts(N, C, SP);
+  float* p0 = reinterpret_cast<float*>(ws);
+  float* p1 = p0 + (long long)C * P;
+  float* coef = p1 + (long long)C * P;
+  if ((SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x) % 16 == 0))
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 4>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1, scale, shift);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<T, 1, 1>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1, scale, shift);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, p0, p1, P, (double)N * (double)SP,
+                     gamma, save_invstd, dgamma, dbeta, coef, (long long)C);
+  const long long total = (long long)N * C * SP;
+  const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) &&
+                  (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
+  if (v4)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(ew_grid(total, 4)), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate, scale, shift);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), dim3(ew_grid(total, 1)), dim3(256), 0, st, dz_in, z, x, save_mean,
+                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate, scale, shift);
+  return gca_launch_status();
+}
+
+extern "C" {
+
+int64_t gca_bn_stats_parts(int64_t N, int64_t C, int64_t SP) { return stats_parts(N, C, SP); }
+
 
 int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
                     const float* gamma, const float* beta, float eps, float momentum,
@@ -416,34 +522,6 @@ int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int6
   return gca_launch_status();
 }
 
-int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
-                     const float* gamma, const float* beta, float eps, float momentum,
-                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
-                     float* save_mean, float* save_invstd, float* scale, float* shift,
-                     const float* x, const float* residual, int relu, int64_t N, int64_t SP, float* z,
-                     int64_t z_batch_stride, void* stream) {
-  if (!x || !z || N <= 0 || SP <= 0 || (double)N * (double)SP != count) return GCA_EINVAL;
-  if (!stat_sum || !stat_sq || P <= 0 || C <= 0 || !scale || !shift) return GCA_EINVAL;
-  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
-  if (N * SP <= BN_SMALL_ELEMS && N * C * SP < (1LL << 31)) {
-    const long long zs = z_batch_stride ? z_batch_stride : C * SP;
-    const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)x | (uintptr_t)z | (uintptr_t)residual) % 16 == 0);
-    hipStream_t st = (hipStream_t)stream;
-    if (v4)
-      hipLaunchKernelGGL((bn_fwd_small_kernel<4>), dim3((unsigned)C), dim3(256), 0, st, stat_sum, stat_sq, (long long)P, count,
-                         gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
-                         (long long*)num_batches_tracked, x, residual, relu, (int)N, (int)C, (int)SP, zs, z);
-    else
-      hipLaunchKernelGGL((bn_fwd_small_kernel<1>), dim3((unsigned)C), dim3(256), 0, st, stat_sum, stat_sq, (long long)P, count,
-                         gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
-                         (long long*)num_batches_tracked, x, residual, relu, (int)N, (int)C, (int)SP, zs, z);
-    return gca_launch_status();
-  }
-  int rc = gca_bn_finalize(stat_sum, stat_sq, P, C, count, gamma, beta, eps, momentum, running_mean, running_var,
-                           num_batches_tracked, save_mean, save_invstd, scale, shift, stream);
-  if (rc) return rc;
-  return gca_bn_apply(x, scale, shift, residual, relu, N, C, SP, z, z_batch_stride, stream);
-}
 
 int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running_mean,
                      const float* running_var, float eps, int64_t C, float* scale, float* shift, void* stream) {
@@ -453,71 +531,53 @@ int gca_bn_fold_eval(const float* gamma, const float* beta, const float* running
   return gca_launch_status();
 }
 
-int gca_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
-                 int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream) {
-  if (!x || !scale || !shift || !z || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
-  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
-  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
-  const long long total = (long long)N * C * SP;
-  const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)x | (uintptr_t)z | (uintptr_t)residual) % 16 == 0);
-  if (v4)
-    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(ew_grid(total, 4)), dim3(256), 0, (hipStream_t)stream, x, scale,
-                       shift, residual, relu, total, (long long)C, (long long)SP, zs, z);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(ew_grid(total, 1)), dim3(256), 0, (hipStream_t)stream, x, scale,
-                       shift, residual, relu, total, (long long)C, (long long)SP, zs, z);
-  return gca_launch_status();
-}
 
 int64_t gca_bn_bwd_ws_bytes(int64_t N, int64_t C, int64_t SP) {
   if (N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
   return (int64_t)sizeof(float) * (2 * C * stats_parts(N, C, SP) + 3 * C);
 }
 
-int gca_bn_bwd(const float* dz_in, const float* z, const float* x, const float* gamma,
+
+int gca_bn_stats(const void* x, int64_t N, int64_t C, int64_t SP, float* stat_sum, float* stat_sq,
+                 int64_t* parts_out, int act_f16, void* stream) {
+  return act_f16 ? bn_stats_t<gca_half>((const gca_half*)x, N, C, SP, stat_sum, stat_sq, parts_out, stream)
+                 : bn_stats_t<float>((const float*)x, N, C, SP, stat_sum, stat_sq, parts_out, stream);
+}
+
+int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,
+                     const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* save_mean, float* save_invstd, float* scale, float* shift,
+                     const void* x, const void* residual, int relu, int64_t N, int64_t SP, void* z,
+                     int64_t z_batch_stride, int act_f16, void* stream) {
+  if (act_f16)
+    return bn_train_fwd_t<gca_half>(stat_sum, stat_sq, P, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                                    num_batches_tracked, save_mean, save_invstd, scale, shift, (const gca_half*)x,
+                                    (const gca_half*)residual, relu, N, SP, (gca_half*)z, z_batch_stride, stream);
+  return bn_train_fwd_t<float>(stat_sum, stat_sq, P, C, count, gamma, beta, eps, momentum, running_mean, running_var,
+                               num_batches_tracked, save_mean, save_invstd, scale, shift, (const float*)x,
+                               (const float*)residual, relu, N, SP, (float*)z, z_batch_stride, stream);
+}
+
+int gca_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,
+                 int relu, int64_t N, int64_t C, int64_t SP, void* z, int64_t z_batch_stride, int act_f16, void* stream) {
+  return act_f16 ? bn_apply_t<gca_half>((const gca_half*)x, scale, shift, (const gca_half*)residual, relu, N, C, SP,
+                                        (gca_half*)z, z_batch_stride, stream)
+                 : bn_apply_t<float>((const float*)x, scale, shift, (const float*)residual, relu, N, C, SP, (float*)z,
+                                     z_batch_stride, stream);
+}
+
+int gca_bn_bwd(const void* dz_in, const void* z, const void* x, const float* gamma,
                const float* save_mean, const float* save_invstd, int relu,
-               int64_t N, int64_t C, int64_t SP, float* dx, float* dgamma, float* dbeta,
-               float* dres, int dres_accumulate, int64_t z_batch_stride, const float* scale, const float* shift,
-               void* ws, void* stream) {
-  if (!dz_in || !x || !save_mean || !save_invstd || !dx || !ws || N <= 0 || C <= 0 || SP <= 0) return GCA_EINVAL;
-  if (relu < 0 || relu > 2 || (relu == 1 && !z) || (relu == 2 && (!scale || !shift))) return GCA_EINVAL;
-  if (relu != 1) z = dz_in;                 // never dereferenced; keeps the alignment test below meaningful
-  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
-  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
-  hipStream_t st = (hipStream_t)stream;
-  if (N * SP <= BN_SMALL_ELEMS && N * C * SP < (1LL << 31)) {
-    const bool s4 = (SP % 4 == 0) && (zs % 4 == 0) &&
-                    (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
-    if (s4)
-      hipLaunchKernelGGL((bn_bwd_small_kernel<4>), dim3((unsigned)C), dim3(256), 0, st, dz_in, z, x, gamma, save_mean, save_invstd,
-                         relu, (int)N, (int)C, (int)SP, zs, dx, dgamma, dbeta, dres, dres_accumulate, scale, shift);
-    else
-      hipLaunchKernelGGL((bn_bwd_small_kernel<1>), dim3((unsigned)C), dim3(256), 0, st, dz_in, z, x, gamma, save_mean, save_invstd,
-                         relu, (int)N, (int)C, (int)SP, zs, dx, dgamma, dbeta, dres, dres_accumulate, scale, shift);
-    return gca_launch_status();
-  }
-  const int P = (int)stats_parts(N, C, SP);
-  float* p0 = reinterpret_cast<float*>(ws);
-  float* p1 = p0 + (long long)C * P;
-  float* coef = p1 + (long long)C * P;
-  if ((SP % 4 == 0) && (zs % 4 == 0) && (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x) % 16 == 0))
-    hipLaunchKernelGGL((bn_reduce_kernel<1, 4>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1, scale, shift);
-  else
-    hipLaunchKernelGGL((bn_reduce_kernel<1, 1>), dim3(P, (unsigned)C), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, relu, (long long)N, (long long)C, (long long)SP, zs, P, p0, p1, scale, shift);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, p0, p1, P, (double)N * (double)SP,
-                     gamma, save_invstd, dgamma, dbeta, coef, (long long)C);
-  const long long total = (long long)N * C * SP;
-  const bool v4 = (SP % 4 == 0) && (zs % 4 == 0) &&
-                  (((uintptr_t)dz_in | (uintptr_t)z | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres) % 16 == 0);
-  if (v4)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(ew_grid(total, 4)), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate, scale, shift);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(ew_grid(total, 1)), dim3(256), 0, st, dz_in, z, x, save_mean,
-                       save_invstd, coef, relu, total, (long long)C, (long long)SP, zs, dx, dres, dres_accumulate, scale, shift);
-  return gca_launch_status();
+               int64_t N, int64_t C, int64_t SP, void* dx, float* dgamma, float* dbeta,
+               void* dres, int dres_accumulate, int64_t z_batch_stride, const float* scale, const float* shift,
+               void* ws, int act_f16, void* stream) {
+  if (act_f16)
+    return bn_bwd_t<gca_half>((const gca_half*)dz_in, (const gca_half*)z, (const gca_half*)x, gamma, save_mean, save_invstd,
+                              relu, N, C, SP, (gca_half*)dx, dgamma, dbeta, (gca_half*)dres, dres_accumulate, z_batch_stride,
+                              scale, shift, ws, stream);
+  return bn_bwd_t<float>((const float*)dz_in, (const float*)z, (const float*)x, gamma, save_mean, save_invstd, relu, N, C, SP,
+                         (float*)dx, dgamma, dbeta, (float*)dres, dres_accumulate, z_batch_stride, scale, shift, ws, stream);
 }
 
 }  // extern "C"

@@ -61,12 +61,16 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // The tile body is a device function so that ONE launch can mix two tile heights (conv_igemm_2phase_kernel below):
 // `bid` is the workgroup's logical id inside its phase, As_/Bs_/taptab the workgroup's LDS (sized by the caller).
-template <int TM, int BN, int FAST, bool VEC, int MATH>
+template <int TM, int BN, int FAST, bool VEC, int MATH, bool H = false>
 __device__ __forceinline__ void igemm_tile(
-    const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
-    const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
+    const void* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
+    const float* __restrict__ bias, void* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, float* __restrict__ slab, const IgemmParams p, int bid,
     float* __restrict__ As_, float* __restrict__ Bs_, int* __restrict__ taptab) {
+  // H: fp16 STORAGE -- the gathered tensor and the destination hold _Float16; every element is widened on load (an fp16
+  // value is exactly hi + lo in the bf16x3 split, so the split-product arithmetic loses nothing of the operands) and the
+  // fp32 accumulator is rounded once on store.  Weights (packed fp32), statistics and split-K slabs stay fp32.
+  constexpr unsigned ES = H ? 2u : 4u;
   constexpr int BM = 32 * TM, TN = BN / 128;
   constexpr int A_F4 = (BM * 4 + 255) / 256;               // float4 loads per thread for the A tile (BM x 16)
   constexpr int B_PER = VEC ? 4 : 8;                       // gathers per thread for the B tile
@@ -107,8 +111,26 @@ __device__ __forceinline__ void igemm_tile(
 
   // Gathers go through a buffer resource: an out-of-range offset returns 0 in hardware, so an invalid
   // window element costs nothing but an OR of all-ones into its 32-bit byte offset -- no post-load select.
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, p.src_bytes, 0x00020000);
-  const unsigned cb4 = (unsigned)colbase * 4u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, p.src_bytes, 0x00020000);
+  const unsigned cb4 = (unsigned)colbase * ES;
+  // one gathered element / four consecutive ones at byte offset `voff` of the source, as fp32
+  auto ld1 = [&](unsigned voff) __attribute__((always_inline)) {
+    if constexpr (H) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
+    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+  };
+  auto ld4 = [&](unsigned voff) __attribute__((always_inline)) {
+    if constexpr (H) {
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const f16x4_t hv = __builtin_bit_cast(f16x4_t, __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0)));
+      return make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+    } else {
+      // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, v[i]) on the elements makes hipcc
+      // (ROCm 7.2) narrow the load to one dword and replicate it.
+      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+      return make_float4(f.x, f.y, f.z, f.w);
+    }
+  };
 
   // tap-INvalidity mask: bit t = 1 -> tap t of this column's window falls outside the source tensor
   // (bits of taps the class does not have, and tap id 63 = padded table row, stay 1)
@@ -176,15 +198,9 @@ __device__ __forceinline__ void igemm_tile(
       if (chkW) k = k & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
       inv = k ? 0 : -1;
     }
-    const unsigned voff = (cb4 + (unsigned)e[i].x) | (unsigned)inv;  // table offsets are in bytes
-    if (VEC) {
-      // NB: bit_cast the WHOLE vector -- __builtin_bit_cast(float, v[i]) on the elements makes hipcc
-      // (ROCm 7.2) narrow the load to one dword and replicate it.
-      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
-      bvec[VEC ? i : 0] = make_float4(f.x, f.y, f.z, f.w);
-    } else {
-      breg[VEC ? 0 : i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
-    }
+    const unsigned voff = (cb4 + (unsigned)(e[i].x >> (H ? 1 : 0))) | (unsigned)inv;  // table offsets are SIGNED fp32 bytes (flipped dgrad taps are negative)
+    if (VEC) bvec[VEC ? i : 0] = ld4(voff);
+    else breg[VEC ? 0 : i] = ld1(voff);
   };
   // piece g of the next tile's fetch, placed after MFMA group g (G groups per tile): table rows + A tile
   // first, then the gathers spread over the following groups, leaving the last group(s) as latency shadow
@@ -364,13 +380,9 @@ __device__ __forceinline__ void igemm_tile(
           if (chkW) k = k & ((unsigned)(iw0 + dw) < (unsigned)p.SW);
           inv = k ? 0 : -1;
         }
-        const unsigned voff = (cb4 + (unsigned)F.e[i].x) | (unsigned)inv;
-        if (VEC) {
-          const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
-          F.bv[VEC ? i : 0] = make_float4(f.x, f.y, f.z, f.w);
-        } else {
-          F.b[VEC ? 0 : i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
-        }
+        const unsigned voff = (cb4 + (unsigned)(F.e[i].x >> (H ? 1 : 0))) | (unsigned)inv;
+        if (VEC) F.bv[VEC ? i : 0] = ld4(voff);
+        else F.b[VEC ? 0 : i] = ld1(voff);
       };
       auto f_all = [&](Fetch& F, int kt) __attribute__((always_inline)) {
         f_table(F, kt); f_a(F, kt);
@@ -547,7 +559,7 @@ __device__ __forceinline__ void igemm_tile(
   if (p.splits > 1) {
     // partial tile -> slab[split][m][n]; bias / accumulate / BN sums happen in conv_splitk_finish_kernel
     float* sl = slab + (long long)split * p.DK * p.Ntot;
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(sl, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(sl, 0, p.slab_bytes, 0x00020000);
     const unsigned rowb = (unsigned)p.Ntot * 4u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -567,7 +579,7 @@ __device__ __forceinline__ void igemm_tile(
   }
   const int DHW = p.DH * p.DW;
   const unsigned DSP = (unsigned)(p.DD * DHW);
-  const unsigned rowb = DSP * 4u;
+  const unsigned rowb = DSP * ES;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, p.dst_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -579,7 +591,7 @@ __device__ __forceinline__ void igemm_tile(
     const int qd = sp / QHW, rr = sp - qd * QHW;
     const int qh = rr / p.QW, qw = rr - qh * p.QW;
     const unsigned dsp = (unsigned)((qd * p.dm_d + p.do_d) * DHW + (qh * p.dm_h + p.do_h) * p.DW + (qw * p.dm_w + p.do_w));
-    const unsigned vb = nv ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * 4u : 0xffffffffu;
+    const unsigned vb = nv ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * ES : 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float old[16];
@@ -588,7 +600,8 @@ __device__ __forceinline__ void igemm_tile(
         for (int r = 0; r < 16; ++r) {
           const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
           const unsigned vo = ro < rows_left ? vb : 0xffffffffu;
-          old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (int)vo, (int)((unsigned)ro * rowb), 0));
+          if constexpr (H) old[r] = (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, (int)vo, (int)((unsigned)ro * rowb), 0));
+          else old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (int)vo, (int)((unsigned)ro * rowb), 0));
         }
       }
 #pragma unroll
@@ -598,7 +611,8 @@ __device__ __forceinline__ void igemm_tile(
         float v = acc[i][j][r];
         if (bias) v += bias[min(mbase + ro + 4 * lh, p.DK - 1)];
         if (p.accumulate) v += old[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)ro * rowb), 0);
+        if constexpr (H) __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rd, (int)vo, (int)((unsigned)ro * rowb), 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)ro * rowb), 0);
       }
     }
   }
@@ -631,16 +645,16 @@ __device__ __forceinline__ void igemm_tile(
   }
 }
 
-template <int TM, int BN, int FAST, bool VEC, int MATH>
+template <int TM, int BN, int FAST, bool VEC, int MATH, bool H = false>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(
-    const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
-    const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
+    const void* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
+    const float* __restrict__ bias, void* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, float* __restrict__ slab, IgemmParams p) {
   __shared__ __attribute__((aligned(16))) float As_[lds_bufs(TM, VEC, MATH) * 32 * TM * lds_pitch(MATH)];
   __shared__ __attribute__((aligned(16))) float Bs_[lds_bufs(TM, VEC, MATH) * BN * lds_pitch(MATH)];
   __shared__ int taptab[64];
-  igemm_tile<TM, BN, FAST, VEC, MATH>(src, apack, table, bias, dst, psum, psq, slab, p, gca_xcd_remap(blockIdx.x, gridDim.x), As_, Bs_,
-                                taptab);
+  igemm_tile<TM, BN, FAST, VEC, MATH, H>(src, apack, table, bias, dst, psum, psq, slab, p, gca_xcd_remap(blockIdx.x, gridDim.x), As_, Bs_,
+                                   taptab);
 }
 
 // Two tile heights in ONE launch: workgroups [0, nA) run TMA-row tiles over the first p.tilesN column tiles, the rest run
@@ -648,8 +662,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(
 // that the last, partly filled wave of tall workgroups leaves idle (a second LAUNCH would wait for that wave to end).
 template <int TMA, int TMB, int FAST, int MATH>
 __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
-    const float* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
-    const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum,
+    const void* __restrict__ src, const float* __restrict__ apack, const int2* __restrict__ table,
+    const float* __restrict__ bias, void* __restrict__ dst, float* __restrict__ psum,
     float* __restrict__ psq, IgemmParams p, int nA, int tilesM_B, int tilesN_B) {
   static_assert(TMB < TMA, "the tail uses the shorter tile");
   __shared__ __attribute__((aligned(16))) float As_[cmax(lds_bufs(TMA, false, MATH) * TMA, lds_bufs(TMB, false, MATH) * TMB) * 32 * lds_pitch(MATH)];
@@ -669,8 +683,9 @@ __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
 // Split-K finishing pass, grid (channels, parts): sum the slabs in fixed order, add bias, (+=) store in
 // NCDHW (through the class's destination map), and emit the BN partial sums [K][parts].
 constexpr int FINISH_CHUNK = 1024;      // columns per finishing block: split-K grids are small, so many short blocks (4 columns per thread)
+template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
-    const float* __restrict__ slab, int splits, const float* __restrict__ bias, float* __restrict__ dst,
+    const float* __restrict__ slab, int splits, const float* __restrict__ bias, T* __restrict__ dst,
     float* __restrict__ psum, float* __restrict__ psq, IgemmParams p) {
   __shared__ double sh[4];
   const int m = blockIdx.x, part = blockIdx.y, P = gridDim.y;
@@ -698,9 +713,9 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
     const int qd = sp / QHW, rr = sp - qd * QHW;
     const int qh = rr / p.QW, qw = rr - qh * p.QW;
     const long long dsp = (long long)(qd * p.dm_d + p.do_d) * DHW + (qh * p.dm_h + p.do_h) * p.DW + (qw * p.dm_w + p.do_w);
-    float* d = dst + ((long long)img * p.DK + m) * DSP + dsp;
-    if (p.accumulate) v += *d;
-    *d = v;
+    T* d = dst + ((long long)img * p.DK + m) * DSP + dsp;
+    if (p.accumulate) v += (float)*d;
+    *d = (T)v;
   }
   if (psum) {
     s = gca_block_sum256_d(s, sh);
@@ -765,8 +780,10 @@ __global__ __launch_bounds__(256) void conv_pack_batched_kernel(const unsigned c
   else pack_elements(j->w, j->packed, p, base + threadIdx.x, 256, end);
 }
 
-__global__ void zero_fill_kernel(float* __restrict__ p, long long n) {
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = 0.f;
+// n32 whole 32-bit words, then (fp16 tensors with an odd element count) one trailing 16-bit element
+__global__ void zero_fill_kernel(unsigned* __restrict__ p, long long n32, int tail16) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n32; i += (long long)gridDim.x * blockDim.x) p[i] = 0u;
+  if (tail16 && blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned short*>(p + n32)[0] = 0;
 }
 
 // ---- launch configuration ------------------------------------------------------------------
@@ -774,6 +791,8 @@ struct IgemmCfg {
   int bm; int bn; int splits; int kt_per_split; int tail_bm; int main_cols; int math;
   int halo;              // 1: conv3d_halo.hip (LDS halo tiles); kt_per_split then counts 16-channel chunks
   int bd, bh, bw;        // halo: box of a tile
+  int h;                 // fp16 storage (gca_set_conv_math(3)): the gather kernels widen on load / round on store and
+                         // multiply in bf16x3 (exact for fp16 operands); the halo kernels multiply on the f16 MFMA (math 3)
 };
 
 
@@ -782,7 +801,7 @@ struct IgemmCfg {
 // gathers for pointwise-in-space classes; the K loop is split when the tile grid cannot occupy the CUs and
 // the partial slabs stay small.  tune code: rows | 1024 for the 256-column variant.
 inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force_bm, int force_splits) {
-  IgemmCfg best{64, 128, 1, nk, 0, 0, 0, 0, 0, 0, 0};
+  IgemmCfg best{64, 128, 1, nk, 0, 0, 0, 0, 0, 0, 0, 0};
   double best_cost = 1e300;
   const bool force_vec = force_bm >= 1024;
   const int force_rows = force_bm & 1023;
@@ -812,7 +831,7 @@ inline IgemmCfg choose_cfg(int M, long long Ntot, int nk, bool vec_ok, int force
       const double eff = (0.55 + 0.1 * tm) * (v ? 1.15 : 1.0) * occ;
       const double work = (double)bm * bn * per;
       const double cost = rounds * work / eff + (s > 1 ? 0.05 * rounds * work + 8.0 * bm * bn : 0.0);
-      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0, 0, 0, 0, 0, 0}; }
+      if (cost < best_cost) { best_cost = cost; best = IgemmCfg{bm, bn, s, per, 0, 0, 0, 0, 0, 0, 0, 0}; }
     }
   }
   return best;
@@ -860,7 +879,7 @@ inline bool halo_geometry(const ClassInfo& c, const IgemmParams& p, int bd, int 
   hp.nchunks = cdiv(c.srcC, 16);
   hp.chunks_per_split = hp.nchunks;
   hp.Mrows = pack_rows(c.M);
-  const long long cs = (long long)p.SD * p.SH * p.SW * 4;
+  const long long cs = (long long)p.SD * p.SH * p.SW * (math == 3 ? 2 : 4);
   const long long pk = (long long)hp.nchunks * c.ntaps * hp.Mrows * halo_row_bytes(math);
   if (cs > 0x7fffffffLL || pk > 0xfffff000LL) return false;
   hp.cs_bytes = (unsigned)cs;
@@ -891,7 +910,7 @@ inline bool halo_pick_box(const ClassInfo& c, const IgemmParams& p, int bn, int 
 inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, const IgemmParams& p, size_t nclasses) {
   int fbm, fs, tail, box;
   tune_of(g, which, fbm, fs, tail, box);
-  const int math = resolve_math(which == 0 ? g->tune_fwd_math : g->tune_dgrad_math);
+  const int math = resolve_math(which == 0 ? g->tune_fwd_math : g->tune_dgrad_math, g->act_f16);
   // ---- LDS-halo kernel: forced by the tune code, or by the heuristic for multi-tap classes with enough channels and tiles
   {
     int bd = box & 255, bh = (box >> 8) & 255, bw = (box >> 16) & 255, rows = fbm & 1023;
@@ -899,7 +918,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
     HaloParams hp;
     if (fbm & 2048) {
       use = bd > 0 && halo_geometry(c, p, bd, bh, bw, math, hp);
-    } else if (fbm == 0 && halo_heuristic_on() && c.ntaps >= 3 && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
+    } else if (fbm == 0 && halo_heuristic_on() && (c.ntaps >= 3 || math == 3) && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
       double cost = 0, cost2 = 0;
       int d2, h2, w2;
       const bool wide = p.DK <= 96 && halo_pick_box(c, p, 256, math, d2, h2, w2, cost2);
@@ -919,7 +938,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
       }
       if (rows >= 32 && rows <= 32 * (bn == 256 ? 4 : 5) && rows % 32 == 0 &&
           halo_lds_bytes(rows, math, hp.P) <= (size_t)(160 << 10) - 1024) {
-        IgemmCfg cf{rows, bn, 1, hp.nchunks, 0, 0, math, 1, bd, bh, bw};
+        IgemmCfg cf{rows, bn, 1, hp.nchunks, 0, 0, math, 1, bd, bh, bw, math == 3};
         const long long tiles = (long long)cdiv(p.DK, rows) * g->N * hp.nbd * hp.nbh * hp.nbw;
         int sp = 1;
         if (fs > 0) sp = fs;
@@ -939,7 +958,9 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
     if (fbm & 2048) { fbm = 0; fs = 0; tail = 0; }       // not runnable as asked: fall back to the gather kernels' heuristic
   }
   IgemmCfg cf = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
-  cf.math = math;
+  cf.math = math == 3 ? 1 : math;
+  cf.h = math == 3;
+  if (cf.h) tail = 0;                                    // (the two-phase launch is built for fp32 storage only)
   // Two-phase launch (measured configurations only; single-class passes, 128-column tiles, no split-K): the first
   // `main_cols` column tiles run with the tall tile, the rest with a short one -- the last, partly filled wave of tall
   // workgroups (up to a quarter of the launch time on the layer-1 shapes) becomes a full wave of short ones.
@@ -958,8 +979,11 @@ inline long long halo_tiles_n(const gca_conv_geom* g, const ClassInfo& c, const 
 
 template <int TM, int BN, int FAST, bool VEC>
 void launch_one(int math, dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
-                float* dst, float* psum, float* psq, float* slab, const IgemmParams& p) {
-  if (math == 1)
+                float* dst, float* psum, float* psq, float* slab, const IgemmParams& p, bool h = false) {
+  if (h)
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 1, true>), grid, dim3(256), 0, st, src, apack, table, bias,
+                       dst, psum, psq, slab, p);
+  else if (math == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 1>), grid, dim3(256), 0, st, src, apack, table, bias,
                        dst, psum, psq, slab, p);
   else if (math == 2)
@@ -974,10 +998,10 @@ template <int TM>
 void launch_tm(const IgemmCfg& c, int fast, dim3 grid, hipStream_t st, const float* src, const float* apack,
                const int2* table, const float* bias, float* dst, float* psum, float* psq, float* slab,
                const IgemmParams& p) {
-  if (c.bn == 256) launch_one<TM, 256, 1, true>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else if (fast == 1) launch_one<TM, 128, 1, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else if (fast == 2) launch_one<TM, 128, 2, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
-  else launch_one<TM, 128, 0, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p);
+  if (c.bn == 256) launch_one<TM, 256, 1, true>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p, c.h);
+  else if (fast == 1) launch_one<TM, 128, 1, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p, c.h);
+  else if (fast == 2) launch_one<TM, 128, 2, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p, c.h);
+  else launch_one<TM, 128, 0, false>(c.math, grid, st, src, apack, table, bias, dst, psum, psq, slab, p, c.h);
 }
 
 inline int stat_parts(const IgemmCfg& c, long long Ntot, long long halo_tiles = 0) {
@@ -1042,8 +1066,12 @@ int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack,
   if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
   int rc = launch_tiles(c.bm, c, fast, dim3((unsigned)nblk), st, src, apack, table, bias, dst, ps, pq, slab, p);
   if (rc || c.splits == 1) return rc;
-  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits,
-                     bias, dst, psum, psq, p);
+  if (c.h)
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<_Float16>, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits,
+                       bias, reinterpret_cast<_Float16*>(dst), psum, psq, p);
+  else
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<float>, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits,
+                       bias, dst, psum, psq, p);
   return gca_launch_status();
 }
 
@@ -1066,8 +1094,12 @@ int run_class_halo(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& c
                        bias, dst, cf.splits > 1 ? nullptr : psum, cf.splits > 1 ? nullptr : psq, slab, st);
   if (rc || cf.splits == 1) return rc;
   p.splits = cf.splits; p.P = hp.g.P;
-  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, cf.splits,
-                     bias, dst, psum, psq, p);
+  if (cf.h)
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<_Float16>, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, cf.splits,
+                       bias, reinterpret_cast<_Float16*>(dst), psum, psq, p);
+  else
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<float>, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, cf.splits,
+                       bias, dst, psum, psq, p);
   return gca_launch_status();
 }
 
@@ -1287,7 +1319,7 @@ int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
     IgemmParams p{};
     class_params(g, which, c, p);
     const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | (cf.halo << 14);
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | (cf.halo << 14) | (cf.h << 15);
     return GCA_OK;
   }
   return GCA_EINVAL;
@@ -1306,8 +1338,11 @@ int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g) {
 int64_t gca_conv_fwd_ws_bytes(const gca_conv_geom* g) { return geom_ok(g) ? ws_bytes_for(g, 0) : GCA_EINVAL; }
 int64_t gca_conv_dgrad_ws_bytes(const gca_conv_geom* g) { return geom_ok(g) ? ws_bytes_for(g, 1) : GCA_EINVAL; }
 
-int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, const int32_t* table,
-                 const float* bias, float* y, float* stat_sum, float* stat_sq, void* ws, void* stream) {
+int gca_conv_fwd(const gca_conv_geom* g, const void* x_, const float* wpack, const int32_t* table,
+                 const float* bias, void* y_, float* stat_sum, float* stat_sq, void* ws, void* stream) {
+  // (activations are fp32, or fp16 when g->act_f16: the kernels below take them as opaque buffers and index in bytes)
+  const float* x = reinterpret_cast<const float*>(x_);
+  float* y = reinterpret_cast<float*>(y_);
   if (!geom_ok(g) || !x || !wpack || !table || !y) return GCA_EINVAL;
   if ((stat_sum == nullptr) != (stat_sq == nullptr)) return GCA_EINVAL;
   std::vector<ClassInfo> cls;
@@ -1324,8 +1359,10 @@ int gca_conv_fwd(const gca_conv_geom* g, const float* x, const float* wpack, con
                    y, stat_sum, stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
 }
 
-int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, const int32_t* table,
-                   float* dx, int accumulate, void* ws, void* stream) {
+int gca_conv_dgrad(const gca_conv_geom* g, const void* dy_, const float* wpack, const int32_t* table,
+                   void* dx_, int accumulate, void* ws, void* stream) {
+  const float* dy = reinterpret_cast<const float*>(dy_);
+  float* dx = reinterpret_cast<float*>(dx_);
   if (!geom_ok(g) || !dy || !wpack || !table || !dx) return GCA_EINVAL;
   if (g->x_batch_stride != 0 && g->x_batch_stride != (long long)g->C * g->D * g->H * g->W) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
@@ -1335,9 +1372,11 @@ int gca_conv_dgrad(const gca_conv_geom* g, const float* dy, const float* wpack, 
   for (const ClassInfo& c : cls) any_empty |= c.ntaps == 0;
   if (any_empty && !accumulate) {          // positions no tap reaches (e.g. 1x1x1 stride 2) get an exact zero
     const long long n = (long long)g->N * g->C * g->D * g->H * g->W;
-    long long blocks = gca_ceil_div(n, 1024);
+    const long long n32 = g->act_f16 ? n / 2 : n;                 // dx holds n elements of 2 (fp16 storage) or 4 bytes
+    long long blocks = gca_ceil_div(n32 + 1, 1024);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dx, n);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<unsigned*>(dx), n32,
+                       g->act_f16 ? (int)(n & 1) : 0);
   }
   const int2* tab = reinterpret_cast<const int2*>(table);
   for (const ClassInfo& c : cls) {

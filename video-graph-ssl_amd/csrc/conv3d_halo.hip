@@ -28,16 +28,22 @@ namespace {
 constexpr int HR = 3;                 // staging rounds per thread: the halo holds up to 128*HR positions
 constexpr int PPAD = 128 * HR;        // staging tasks per channel half (tasks beyond the halo write the dump slot)
 
-constexpr int rowb(int math) { return math == 2 ? 96 : 64; }          // bytes of one 16-k row: fp32 / hi+lo / hi+mid+lo
-constexpr int pitchb(int math) { return rowb(math) + 16; }            // 80 / 112 B: odd number of 16-B slots -> conflict-free b128 reads
-constexpr int nparts(int math) { return math == 0 ? 1 : (math == 2 ? 3 : 2); }
+// arithmetic 3 = fp16 STORAGE: activations are _Float16 in HBM, products on v_mfma_f32_32x32x16_f16, fp32 accumulation
+constexpr int rowb(int math) { return math == 3 ? 32 : (math == 2 ? 96 : 64); }   // bytes of one 16-k row: fp16 / fp32 / hi+lo / hi+mid+lo
+constexpr int pitchb(int math) { return rowb(math) + 16; }            // 48 / 80 / 112 B: odd number of 16-B slots -> conflict-free b128 reads
+constexpr int nparts(int math) { return (math == 0 || math == 3) ? 1 : (math == 2 ? 3 : 2); }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned short f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
+__device__ __forceinline__ float f16_val(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
 
 // (second launch bound = waves per SIMD: two workgroups per CU whenever the accumulators leave room for it)
 template <int TM, int TN, int MATH>
 __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
-    const float* __restrict__ src, const unsigned char* __restrict__ apack, const int* __restrict__ tapdelta,
-    const float* __restrict__ bias, float* __restrict__ dst, float* __restrict__ psum, float* __restrict__ psq,
+    const void* __restrict__ src, const unsigned char* __restrict__ apack, const int* __restrict__ tapdelta,
+    const float* __restrict__ bias, void* __restrict__ dst, float* __restrict__ psum, float* __restrict__ psq,
     float* __restrict__ slab, const HaloParams hp) {
+  constexpr bool F16 = MATH == 3;                               // activations (src, dst) are fp16
+  constexpr unsigned ES = F16 ? 2u : 4u;
   constexpr int BM = 32 * TM;                                   // x 128*TN columns: TN column tiles of 32 per wave
   constexpr int ROWB = rowb(MATH), PITCH = pitchb(MATH), NP = nparts(MATH);
   constexpr int RPC = ROWB / 16;                                // 16-byte pieces per packed row
@@ -72,7 +78,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
   }
 
   // ---- staging tasks of this thread: (halo position, channel half) per round, fixed for the whole K loop
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, p.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, p.src_bytes, 0x00020000);
   unsigned hvoff[HR];          // byte offset of channel 0 of the chunk at this position, all-ones when outside the tensor
   unsigned hwoff[HR];          // LDS byte offset of the task's slot
   int hhalf[HR];
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
       const int sd = s0d + zd, sh = s0h + zh, sw = s0w + zw;
       const bool ok = pos < hp.P && (unsigned)sd < (unsigned)p.SD && (unsigned)sh < (unsigned)p.SH && (unsigned)sw < (unsigned)p.SW;
       const unsigned e = (unsigned)((long long)img * p.src_nstride) + (unsigned)((sd * p.SH + sh) * p.SW + sw);
-      hvoff[r] = ok ? e * 4u + (unsigned)half * 8u * hp.cs_bytes : 0xffffffffu;
+      hvoff[r] = ok ? e * ES + (unsigned)half * 8u * hp.cs_bytes : 0xffffffffu;
       hwoff[r] = (unsigned)(pos < hp.P ? pos : hp.P) * PITCH + (unsigned)half * (MATH == 0 ? 32u : 16u);
       hhalf[r] = half;
     }
@@ -115,14 +121,18 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const unsigned v = (c0 + 8 * hhalf[r] + j < p.SC) ? hvoff[r] : 0xffffffffu;
-        hreg[r][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)v, (int)((unsigned)(c0 + j) * hp.cs_bytes), 0));
+        if (F16) hreg[r][j] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)v, (int)((unsigned)(c0 + j) * hp.cs_bytes), 0));
+        else hreg[r][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)v, (int)((unsigned)(c0 + j) * hp.cs_bytes), 0));
       }
   };
   auto halo_store = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
       unsigned char* d = Hs + hwoff[r];
-      if (MATH == 0) {
+      if (F16) {                                  // 8 channels of one position: 8 halves = one 16-byte store
+        auto u = [&](int j) __attribute__((always_inline)) { return __float_as_uint(hreg[r][j]); };
+        *reinterpret_cast<uint4*>(d) = make_uint4(u(0) | (u(1) << 16), u(2) | (u(3) << 16), u(4) | (u(5) << 16), u(6) | (u(7) << 16));
+      } else if (MATH == 0) {
         *reinterpret_cast<float4*>(d) = make_float4(hreg[r][0], hreg[r][1], hreg[r][2], hreg[r][3]);
         *reinterpret_cast<float4*>(d + 16) = make_float4(hreg[r][4], hreg[r][5], hreg[r][6], hreg[r][7]);
       } else if (MATH == 2) {
@@ -198,7 +208,10 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
   auto mma_group = [&](int i, const float4 (&af)[NQ], const float4 (&bf)[TN][NQ]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      if constexpr (MATH == 0) {
+      if constexpr (MATH == 3) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[j][0]),
+                                                          acc[i][j], 0, 0, 0);
+      } else if constexpr (MATH == 0) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q].x, bf[j][q].x, acc[i][j], 0, 0, 0);
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
   if (p.splits > 1) {
     // partial tile -> slab[split][m][n], n = the flat column index of conv3d.hip (conv_splitk_finish_kernel finishes it)
     float* sl = slab + (long long)split * p.DK * p.Ntot;
-    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(sl, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(sl, 0, p.slab_bytes, 0x00020000);
     const unsigned rowb_ = (unsigned)p.Ntot * 4u;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -304,12 +317,12 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
   }
   const int DHW = p.DH * p.DW;
   const unsigned DSP = (unsigned)(p.DD * DHW);
-  const unsigned rowb_ = DSP * 4u;
+  const unsigned rowb_ = DSP * ES;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, p.dst_bytes, 0x00020000);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const unsigned dsp = (unsigned)((cq[j][0] * p.dm_d + p.do_d) * DHW + (cq[j][1] * p.dm_h + p.do_h) * p.DW + (cq[j][2] * p.dm_w + p.do_w));
-    const unsigned vb = cval[j] ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * 4u : 0xffffffffu;
+    const unsigned vb = cval[j] ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * ES : 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       float old[16];
@@ -318,7 +331,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
         for (int r = 0; r < 16; ++r) {
           const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
           const unsigned vo = ro < rows_left ? vb : 0xffffffffu;
-          old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (int)vo, (int)((unsigned)ro * rowb_), 0));
+          if (F16) old[r] = f16_val((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rd, (int)vo, (int)((unsigned)ro * rowb_), 0));
+          else old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, (int)vo, (int)((unsigned)ro * rowb_), 0));
         }
       }
 #pragma unroll
@@ -328,7 +342,8 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
         float v = acc[i][j][r];
         if (bias) v += bias[min(mbase + ro + 4 * lh, p.DK - 1)];
         if (p.accumulate) v += old[r];
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)ro * rowb_), 0);
+        if (F16) __builtin_amdgcn_raw_buffer_store_b16(f16_bits(v), rd, (int)vo, (int)((unsigned)ro * rowb_), 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)ro * rowb_), 0);
       }
     }
   }
@@ -361,11 +376,11 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
 }
 
 template <int TM, int TN>
-int launch_halo_math(int math, dim3 grid, size_t lds, hipStream_t st, const float* src, const unsigned char* apack,
-                     const int* tapdelta, const float* bias, float* dst, float* ps, float* pq, float* slab,
+int launch_halo_math(int math, dim3 grid, size_t lds, hipStream_t st, const void* src, const unsigned char* apack,
+                     const int* tapdelta, const float* bias, void* dst, float* ps, float* pq, float* slab,
                      const HaloParams& hp) {
   // dynamic LDS beyond the default 64 KB window needs the attribute (once per instantiation; not a stream operation)
-  static bool raised[3] = {false, false, false};
+  static bool raised[4] = {false, false, false, false};
 #define GCA_HK(M)                                                                                                          \
   {                                                                                                                        \
     if (lds > (48u << 10) && !raised[M]) {                                                                                 \
@@ -379,6 +394,7 @@ int launch_halo_math(int math, dim3 grid, size_t lds, hipStream_t st, const floa
   switch (math) {
     case 0: GCA_HK(0) break;
     case 1: GCA_HK(1) break;
+    case 3: GCA_HK(3) break;
     default: GCA_HK(2) break;
   }
 #undef GCA_HK
@@ -392,8 +408,8 @@ namespace gca_conv {
 size_t halo_lds_bytes(int bm, int math, int P) { return (size_t)(2 * bm + P + 1) * pitchb(math) + 64 * sizeof(int); }
 int halo_max_positions() { return PPAD; }
 
-int halo_launch(const HaloCfg& c, const HaloParams& hp_in, const float* src, const unsigned char* apack, const int* tapdelta,
-                const float* bias, float* dst, float* psum, float* psq, float* slab, hipStream_t st) {
+int halo_launch(const HaloCfg& c, const HaloParams& hp_in, const void* src, const unsigned char* apack, const int* tapdelta,
+                const float* bias, void* dst, float* psum, float* psq, float* slab, hipStream_t st) {
   HaloParams hp = hp_in;
   const size_t lds = halo_lds_bytes(c.bm, c.math, hp.P);
   const long long nblk = (long long)hp.g.tilesM * hp.g.tilesN * hp.g.splits;

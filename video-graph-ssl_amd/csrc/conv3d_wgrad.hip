@@ -30,6 +30,7 @@ struct WgradParams {
   int kt_per_split, kt_total;
   int chk;
   int math;                 // arithmetic of this launch (host side only)
+  int half;                 // x and dy are fp16 in HBM (host side only)
   unsigned Ktot;            // NB*OD*OH*OW (GEMM K) -- < 2^30
   unsigned x_nstride;       // elements between clips of x
   unsigned x_bytes, dy_bytes, slab_bytes;
@@ -59,10 +60,13 @@ __device__ __forceinline__ MaskT tap_valid_mask(const WgradParams& p, int id0, i
 // BVEC (pointwise-in-space convs: kh = kw = 1, unit spatial stride, no spatial padding): a table row's 4
 // consecutive positions are 4 consecutive floats of X, so the gather uses float4 loads too (and shares the
 // position arithmetic with the dY loads).
-template <int WM, int WN, int TM, int TN, bool AVEC, int FAST, bool BVEC, int MATH>
+// H: fp16 storage of x and dy (gca_set_conv_math(3)): elements are widened on load, the arithmetic (MATH) is unchanged --
+// an fp16 value is exactly hi + lo in the bf16x3 split; dW is accumulated and written in fp32.
+template <int WM, int WN, int TM, int TN, bool AVEC, int FAST, bool BVEC, int MATH, bool H = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
-    const float* __restrict__ x, const float* __restrict__ dy, const int2* __restrict__ table,
+    const void* __restrict__ x, const void* __restrict__ dy, const int2* __restrict__ table,
     float* __restrict__ slab, WgradParams p) {
+  constexpr unsigned ES = H ? 2u : 4u;
   static_assert(WM * WN == 4, "4 waves");
   static_assert(32 * WN * TN <= TABLE_PAD_W, "the row table is padded for tiles up to TABLE_PAD_W columns");
   constexpr int BM = 32 * WM * TM, BNW = 32 * WN * TN;
@@ -98,8 +102,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const unsigned OSP = (unsigned)(p.OD * p.OH * p.OW);
   const int HW = p.H * p.W;
   const bool chkD = p.chk & 1, chkH = p.chk & 2, chkW = p.chk & 4;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dy), 0, p.dy_bytes, 0x00020000);
+  auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff) __attribute__((always_inline)) {
+    if constexpr (H) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
+    else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
+  };
+  auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff) __attribute__((always_inline)) {
+    if constexpr (H) {
+      typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const f16x4_t hv = __builtin_bit_cast(f16x4_t, __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0)));
+      return make_float4((float)hv.x, (float)hv.y, (float)hv.z, (float)hv.w);
+    } else {
+      // whole-vector bit_cast: element-wise __builtin_bit_cast miscompiles to a replicated dword load (ROCm 7.2)
+      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+      return make_float4(f.x, f.y, f.z, f.w);
+    }
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -118,8 +138,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   float breg[BVEC ? 1 : B_PER];
   float4 bvec[BVEC ? B_PER : 1];
   const int a_rows_left = p.K - (tileM * BM + (AVEC ? ga : g));     // dY row (32*i | 8*i) of this thread is real iff < this
-  const unsigned a_row0 = (unsigned)(tileM * BM + (AVEC ? ga : g)) * OSP * 4u;
-  const unsigned a_step = (AVEC ? 32u : 8u) * OSP * 4u;
+  const unsigned a_row0 = (unsigned)(tileM * BM + (AVEC ? ga : g)) * OSP * ES;
+  const unsigned a_step = (AVEC ? 32u : 8u) * OSP * ES;
 
   // The next tile's fetch is split into pieces that are issued BETWEEN the MFMA groups of the current tile (see
   // conv3d.hip): prep = position arithmetic + window mask, then the dY loads, then the X gathers in chunks.
@@ -134,12 +154,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       const unsigned kc = nx_av ? kp : 0u;
       img4 = gca_fdiv(kc, p.m_osp);
       o4 = kc - img4 * OSP;
-      nx_abase = (img4 * (unsigned)p.K * OSP + o4) * 4u + a_row0;
+      nx_abase = (img4 * (unsigned)p.K * OSP + o4) * ES + a_row0;
     }
     if (BVEC) {                                                 // X rows for the same 4 positions
       const unsigned od = gca_fdiv(o4, p.m_ohw), r = o4 - od * p.m_ohw.d;
       const int id0 = (int)od * p.sd - p.pd;
-      nx_bbase = (img4 * p.x_nstride + (unsigned)(id0 * HW) + r) * 4u;
+      nx_bbase = (img4 * p.x_nstride + (unsigned)(id0 * HW) + r) * ES;
       nx_ilo = nx_av ? ~tap_valid_mask<unsigned>(p, id0, 0, 0, chkD, false, false) : 0xffffffffu;
       return;
     }
@@ -149,11 +169,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const unsigned kc = nx_kv ? kp : 0u;
     const unsigned img = gca_fdiv(kc, p.m_osp);
     const unsigned o = kc - img * OSP;
-    if (!AVEC) { nx_av = nx_kv; nx_abase = (img * (unsigned)p.K * OSP + o) * 4u + a_row0; }
+    if (!AVEC) { nx_av = nx_kv; nx_abase = (img * (unsigned)p.K * OSP + o) * ES + a_row0; }
     const unsigned od = gca_fdiv(o, p.m_ohw), r = o - od * p.m_ohw.d;
     const unsigned oh = gca_fdiv(r, p.m_ow), ow = r - oh * (unsigned)p.OW;
     nx_id0 = (int)od * p.sd - p.pd; nx_ih0 = (int)oh * p.sh - p.ph; nx_iw0 = (int)ow * p.sw - p.pw;
-    nx_bbase = (img * p.x_nstride + (unsigned)(nx_id0 * HW + nx_ih0 * p.W + nx_iw0)) * 4u;
+    nx_bbase = (img * p.x_nstride + (unsigned)(nx_id0 * HW + nx_ih0 * p.W + nx_iw0)) * ES;
     if (FAST == 1) nx_ilo = nx_kv ? ~tap_valid_mask<unsigned>(p, nx_id0, nx_ih0, nx_iw0, chkD, chkH, chkW) : 0xffffffffu;
     if (FAST == 2) {
       const unsigned long long inval = nx_kv ? ~tap_valid_mask<unsigned long long>(p, nx_id0, nx_ih0, nx_iw0, chkD, chkH, chkW) : ~0ull;
@@ -164,21 +184,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 #pragma unroll
     for (int i = 0; i < A_PER; ++i) {
       const unsigned voff = (nx_av && (AVEC ? 32 : 8) * i < a_rows_left) ? nx_abase + (unsigned)i * a_step : 0xffffffffu;
-      if (AVEC) {
-        // whole-vector bit_cast: element-wise __builtin_bit_cast miscompiles to a replicated dword load (ROCm 7.2)
-        const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, (int)voff, 0, 0));
-        avec[AVEC ? i : 0] = make_float4(f.x, f.y, f.z, f.w);
-      } else {
-        areg[AVEC ? 0 : i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, (int)voff, 0, 0));
-      }
+      if (AVEC) avec[AVEC ? i : 0] = ld4(ry, voff);
+      else areg[AVEC ? 0 : i] = ld1(ry, voff);
     }
   };
   auto issue_b = [&](int j) __attribute__((always_inline)) {     // X window element(s) of table row n' (j: constant)
     if (BVEC) {
       const int2 e = Ts[ga + 32 * j];                            // x: byte offset, y: tap id in the low bits
-      const unsigned voff = (nx_bbase + (unsigned)e.x) | (unsigned)__builtin_amdgcn_sbfe((int)nx_ilo, e.y, 1);
-      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)voff, 0, 0));
-      bvec[BVEC ? j : 0] = make_float4(f.x, f.y, f.z, f.w);
+      const unsigned voff = (nx_bbase + (unsigned)(e.x >> (H ? 1 : 0))) | (unsigned)__builtin_amdgcn_sbfe((int)nx_ilo, e.y, 1);
+      bvec[BVEC ? j : 0] = ld4(rx, voff);
       return;
     }
     const int2 e = Ts[g + 8 * j];
@@ -196,7 +210,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
       if (chkW) ok = ok & ((unsigned)(nx_iw0 + dw) < (unsigned)p.W);
       inv = ok ? 0u : 0xffffffffu;
     }
-    breg[BVEC ? 0 : j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (int)((nx_bbase + (unsigned)e.x) | inv), 0, 0));
+    breg[BVEC ? 0 : j] = ld1(rx, (nx_bbase + (unsigned)(e.x >> (H ? 1 : 0))) | inv);
   };
   constexpr int G = (MATH ? WBK / 16 : WBK / 8) * TM * TN;       // MFMA groups (4 exact / 3 bf16x3 MFMAs each) per tile
   constexpr int GSPAN = G > 2 ? G - 2 : 1;
@@ -496,7 +510,8 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   p.Ktot = (unsigned)((long long)g->N * osp);
   const long long cdhw = (long long)g->C * g->D * g->H * g->W;
   p.x_nstride = (unsigned)(g->x_batch_stride ? g->x_batch_stride : cdhw);
-  const long long xb = (long long)g->N * p.x_nstride * 4, yb = (long long)g->N * g->K * osp * 4;
+  const long long es = g->act_f16 ? 2 : 4;                       // fp16 storage of x and dy
+  const long long xb = (long long)g->N * p.x_nstride * es, yb = (long long)g->N * g->K * osp * es;
   const long long sb = (long long)g->K * p.Kred * 4;
   p.x_bytes = xb > 0xfffff000LL ? 0xfffff000u : (unsigned)xb;
   p.dy_bytes = yb > 0xfffff000LL ? 0xfffff000u : (unsigned)yb;
@@ -537,7 +552,9 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   if (g->tune_wgrad_splits > 0) want = g->tune_wgrad_splits < p.kt_total ? g->tune_wgrad_splits : p.kt_total;
   p.kt_per_split = (int)gca_ceil_div(p.kt_total, want);
   p.splits = (int)gca_ceil_div(p.kt_total, p.kt_per_split);
-  p.math = resolve_math(g->tune_wgrad_math);
+  p.math = resolve_math(g->tune_wgrad_math, g->act_f16);
+  p.half = p.math == 3;
+  if (p.half) p.math = 1;                     // fp16 operands multiplied as exact bf16 hi + lo pairs
   p.chk = ((g->pd > 0 || (g->OD - 1) * g->sd + g->kd > g->D) ? 1 : 0) |
           ((g->ph > 0 || (g->OH - 1) * g->sh + g->kh > g->H) ? 2 : 0) |
           ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
@@ -555,7 +572,12 @@ void launch_wm(int avec, dim3 grid, hipStream_t st, const float* x, const float*
 template <int WM, int WN, int TM, int TN, int FAST>
 void launch_w(int avec, dim3 grid, hipStream_t st, const float* x, const float* dy, const int2* t, float* slab,
               const WgradParams& p) {
-  if (p.math == 1) launch_wm<WM, WN, TM, TN, FAST, 1>(avec, grid, st, x, dy, t, slab, p);
+  if (p.half) {
+    if (avec == 2 && FAST == 1)
+      hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, 1, true, 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+    else if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST, false, 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST, false, 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+  } else if (p.math == 1) launch_wm<WM, WN, TM, TN, FAST, 1>(avec, grid, st, x, dy, t, slab, p);
   else if (p.math == 2) launch_wm<WM, WN, TM, TN, FAST, 2>(avec, grid, st, x, dy, t, slab, p);
   else launch_wm<WM, WN, TM, TN, FAST, 0>(avec, grid, st, x, dy, t, slab, p);
 }
@@ -599,8 +621,10 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
   return GCA_OK;
 }
 
-int gca_conv_wgrad(const gca_conv_geom* g, const float* x, const float* dy, const int32_t* table,
+int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream) {
+  const float* x = reinterpret_cast<const float*>(x_);      // opaque to the host side: the kernels index in bytes
+  const float* dy = reinterpret_cast<const float*>(dy_);
   if (!geom_ok(g) || !x || !dy || !table || !dw || !ws) return GCA_EINVAL;
   WgradPlan pl{};
   wgrad_plan(g, pl);

@@ -15,11 +15,14 @@ namespace gca_conv {
 // fp32 operands split in the kernel into 2 / 3 bf16 parts, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 // Defined in conv3d.hip (gca_set_conv_math / GCA_CONV_MATH).
 int conv_math();
-constexpr int math_parts(int math) { return math == 2 ? 3 : 2; }   // bf16 parts per fp32 operand element
+constexpr int math_parts(int math) { return math == 2 ? 3 : 2; }   // (mode 3 never reaches the gather kernels: they run it as 1)   // bf16 parts per fp32 operand element
 // arithmetic of one pass: the tune_*_math override (1 + m) when m is at least as accurate as the mode in force
 inline int math_rank(int m) { return m == 0 ? 2 : m == 2 ? 1 : 0; }     // f32 > bf16x6 > bf16x3
-inline int resolve_math(int tune_math) {
+// act_f16: the activations of this convolution are fp16 in HBM (gca_conv_geom.act_f16) -> arithmetic 3: the f16 MFMA in
+// the LDS-halo kernels, exact bf16 hi + lo pairs of the widened operands in the gather / wgrad kernels; nothing to pin
+inline int resolve_math(int tune_math, int act_f16 = 0) {
   const int mode = conv_math();
+  if (act_f16) return 3;
   if (tune_math >= 1 && tune_math <= 3 && math_rank(tune_math - 1) >= math_rank(mode)) return tune_math - 1;
   return mode;
 }
@@ -93,6 +96,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   if (in_elems >= (1LL << 30) || out_elems >= (1LL << 30)) return false;
   for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && (v >> 10) <= 2)) return false;
   for (int v : {g->tune_fwd_box, g->tune_dgrad_box}) if (v < 0 || v > 0xffffff) return false;
+  if (g->act_f16 != 0 && g->act_f16 != 1) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
   if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 10) return false;
   for (int v : {g->tune_fwd_math, g->tune_dgrad_math, g->tune_wgrad_math}) if (v < 0 || v > 3) return false;

@@ -30,7 +30,7 @@ struct HaloCfg {
 // One thread per (step, row, pair of channels) of the halo pack (PackParams fmt 1).
 __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, unsigned char* __restrict__ packed,
                                                    const PackParams& p, long long first, long long step, long long end) {
-  const int rowbytes = p.math == 2 ? 96 : 64;
+  const int rowbytes = p.math == 3 ? 32 : (p.math == 2 ? 96 : 64);
   for (long long i = first; i < end; i += step) {
     const int kp = (int)(i & 7);                 // channel pair inside the chunk
     const long long rowi = i >> 3;
@@ -46,7 +46,10 @@ __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, 
       if (ch + 1 < p.SC) v1 = w[(long long)(ch + 1) * p.s_ch + tap + (long long)m * p.s_m];
     }
     unsigned char* row = packed + rowi * rowbytes;
-    if (p.math == 0) {
+    if (p.math == 3) {                             // fp16 weights for v_mfma_f32_32x32x16_f16 (fp32 masters stay in the arena)
+      const unsigned lo = __builtin_bit_cast(unsigned short, (_Float16)v0), hi = __builtin_bit_cast(unsigned short, (_Float16)v1);
+      *reinterpret_cast<unsigned*>(row + 4 * kp) = lo | (hi << 16);
+    } else if (p.math == 0) {
       *reinterpret_cast<float2*>(row + 8 * kp) = make_float2(v0, v1);
     } else if (p.math == 2) {
       unsigned h, md, l;
@@ -63,10 +66,10 @@ __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, 
   }
 }
 
-inline int halo_row_bytes(int math) { return math == 2 ? 96 : 64; }
+inline int halo_row_bytes(int math) { return math == 3 ? 32 : (math == 2 ? 96 : 64); }
 size_t halo_lds_bytes(int bm, int math, int P);
 int halo_max_positions();
-int halo_launch(const HaloCfg& c, const HaloParams& hp, const float* src, const unsigned char* apack, const int* tapdelta,
-                const float* bias, float* dst, float* psum, float* psq, float* slab, hipStream_t st);
+int halo_launch(const HaloCfg& c, const HaloParams& hp, const void* src, const unsigned char* apack, const int* tapdelta,
+                const float* bias, void* dst, float* psum, float* psq, float* slab, hipStream_t st);
 
 }  // namespace gca_conv

@@ -27,6 +27,7 @@ struct IgemmParams {
   long long src_nstride;   // elements between consecutive images of the gathered tensor
   unsigned src_bytes;      // extent of the gathered tensor for the buffer resource (range check)
   unsigned dst_bytes;      // extent of the destination tensor
+  unsigned slab_bytes;     // extent of one fp32 split-K slab [DK][Ntot]
 };
 
 // ---- host side: problem classes ---------------------------------------------------------------
@@ -129,10 +130,13 @@ inline void class_params(const gca_conv_geom* g, int which, const ClassInfo& c, 
   p.src_nstride = which == 0 ? (g->x_batch_stride ? g->x_batch_stride : (long long)g->C * g->D * g->H * g->W)
                              : (long long)g->K * g->OD * g->OH * g->OW;
   {
-    const long long span = (long long)g->N * p.src_nstride * 4;
+    const long long es = g->act_f16 ? 2 : 4;                                    // activation element size (fp16 storage: 2)
+    const long long span = (long long)g->N * p.src_nstride * es;
     p.src_bytes = span > 0xfffff000LL ? 0xfffff000u : (unsigned)span;
-    const long long dspan = (long long)g->N * p.DK * p.DD * p.DH * p.DW * 4;     // destination tensor (or one slab)
+    const long long dspan = (long long)g->N * p.DK * p.DD * p.DH * p.DW * es;    // destination tensor
     p.dst_bytes = dspan > 0xfffff000LL ? 0xfffff000u : (unsigned)dspan;
+    const long long sspan = (long long)p.DK * p.Ntot * 4;                        // one split-K slab (always fp32)
+    p.slab_bytes = sspan > 0xfffff000LL ? 0xfffff000u : (unsigned)sspan;
   }
   // bounds tests: skip a dimension when every tap of every column stays inside by construction
   const int lim[3] = {p.SD, p.SH, p.SW};

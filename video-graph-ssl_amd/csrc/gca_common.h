@@ -75,3 +75,27 @@ __device__ __forceinline__ double gca_block_sum256_d(double v, double* sh) {
   __syncthreads();
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
+
+// ---- activation storage: fp32, or IEEE fp16 (the fp16-storage path: 2 bytes per activation element in HBM, every kernel
+// widens on load and rounds once on store; arithmetic, statistics and parameters stay fp32 / fp64)
+typedef _Float16 gca_half;
+template <typename T> struct gca_act;
+template <> struct gca_act<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+};
+template <> struct gca_act<gca_half> {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ float ld(const gca_half* p) { return (float)*p; }
+  static __device__ __forceinline__ void st(gca_half* p, float v) { *p = (gca_half)v; }
+  static __device__ __forceinline__ float4 ld4(const gca_half* p) {
+    const h4 v = *reinterpret_cast<const h4*>(p);
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+  }
+  static __device__ __forceinline__ void st4(gca_half* p, float4 v) {
+    h4 o; o.x = (gca_half)v.x; o.y = (gca_half)v.y; o.z = (gca_half)v.z; o.w = (gca_half)v.w;
+    *reinterpret_cast<h4*>(p) = o;
+  }
+};

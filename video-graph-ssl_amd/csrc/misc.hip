@@ -157,6 +157,18 @@ __global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n, float a) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] += a * x[i];
 }
+// fp16-storage activations: gradient accumulation y += a*x in fp32, one rounding; and the fp32 -> fp16 cast of the input clips
+__global__ void axpy_f16_kernel(gca_half* __restrict__ y, const gca_half* __restrict__ x, long long n, float a) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = (gca_half)((float)y[i] + a * (float)x[i]);
+}
+// rows of re elements (re % 4 == 0), source rows src_stride apart (a channel slice of a wider clip batch), dense output
+__global__ void cast_f16_kernel(const float* __restrict__ x, long long re4, long long src_stride, gca_half* __restrict__ y) {
+  const float* xr = x + (long long)blockIdx.y * src_stride;
+  gca_half* yr = y + (long long)blockIdx.y * re4 * 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < re4; i += (long long)gridDim.x * blockDim.x)
+    gca_act<gca_half>::st4(yr + 4 * i, *reinterpret_cast<const float4*>(xr + 4 * i));
+}
 __global__ void scale_kernel(float* __restrict__ y, long long n, float a) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] *= a;
 }
@@ -250,6 +262,22 @@ int gca_fill(float* p, int64_t n, float v, void* stream) {
 int gca_axpy(float* y, const float* x, int64_t n, float a, void* stream) {
   if (!y || !x || n <= 0) return GCA_EINVAL;
   hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, x, (long long)n, a);
+  return gca_launch_status();
+}
+int gca_axpy_f16(void* y, const void* x, int64_t n, float a, void* stream) {
+  if (!y || !x || n <= 0) return GCA_EINVAL;
+  hipLaunchKernelGGL(axpy_f16_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (gca_half*)y, (const gca_half*)x,
+                     (long long)n, a);
+  return gca_launch_status();
+}
+int gca_cast_f16(const float* x, int64_t rows, int64_t row_elems, int64_t src_row_stride, void* y, void* stream) {
+  if (!y || !x || rows <= 0 || rows > 65535 || row_elems <= 0 || row_elems % 4 || src_row_stride < row_elems ||
+      src_row_stride % 4 || ((uintptr_t)x % 16) || ((uintptr_t)y % 8))
+    return GCA_EINVAL;
+  const long long re4 = row_elems / 4;
+  const unsigned bx = (unsigned)(re4 / 256 + 1 < 4096 ? re4 / 256 + 1 : 4096);
+  hipLaunchKernelGGL(cast_f16_kernel, dim3(bx, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, re4,
+                     (long long)src_row_stride, (gca_half*)y);
   return gca_launch_status();
 }
 int gca_scale(float* y, int64_t n, float a, void* stream) {

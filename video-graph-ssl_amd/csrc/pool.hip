@@ -15,9 +15,9 @@ struct PoolMagic {
 // One thread per output element.  Tie break = first maximum in (d,h,w) scan order and NaN propagates, exactly
 // as ATen's max_pool3d_with_indices (val > max || isnan(val)).  KD/KH/KW > 0: window fully unrolled with
 // clamped (always in-bounds) loads, so all taps are in flight at once; 0 = run-time window.
-template <int KD, int KH, int KW>
-__global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ x,
-                                                            float* __restrict__ y, int* __restrict__ argmax,
+template <typename T, int KD, int KH, int KW>
+__global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, PoolMagic q, const T* __restrict__ x,
+                                                            T* __restrict__ y, int* __restrict__ argmax,
                                                             unsigned total, const float* __restrict__ scale,
                                                             const float* __restrict__ shift) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
   const int od = (int)gca_fdiv(o, q.ohw), r = (int)(o - (unsigned)od * q.ohw.d);
   const int oh = (int)gca_fdiv((unsigned)r, q.ow), ow = r - oh * g.OW;
   const int d0 = od * g.sd - g.pd, h0 = oh * g.sh - g.ph, w0 = ow * g.sw - g.pw;
-  const float* xp = x + (long long)plane * ((long long)g.D * g.H * g.W);
+  const T* xp = x + (long long)plane * ((long long)g.D * g.H * g.W);
   float best = -INFINITY;
   int bi = (max(d0, 0) * g.H + max(h0, 0)) * g.W + max(w0, 0);
   if (KD > 0) {
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
           const int d = d0 + a, h = h0 + b, w = w0 + c;
           const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
           const int idx = (d * g.H + h) * g.W + w;
-          const float v = GCA_POOL_VAL(xp[ok ? idx : bi]);
+          const float v = GCA_POOL_VAL((float)xp[ok ? idx : bi]);
           if (ok && (v > best || isnan(v))) { best = v; bi = idx; }
         }
   } else {
@@ -53,21 +53,21 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
       for (int h = max(h0, 0); h < h1; ++h)
         for (int w = max(w0, 0); w < w1; ++w) {
           const int idx = (d * g.H + h) * g.W + w;
-          const float v = GCA_POOL_VAL(xp[idx]);
+          const float v = GCA_POOL_VAL((float)xp[idx]);
           if (v > best || isnan(v)) { best = v; bi = idx; }
         }
   }
 #undef GCA_POOL_VAL
-  y[i] = best;
+  y[i] = (T)best;
   if (argmax) argmax[i] = bi;
 }
 
 // One thread per INPUT element: gathers from the (few) windows that cover it, no atomics (deterministic, fixed
 // summation order od,oh,ow).  CD/CH/CW = ceil(k/s) per axis is the most windows that can cover one element;
 // > 0: fully unrolled with clamped loads (argmax and dy of all candidates in flight together); 0 = run-time.
-template <int CD, int CH, int CW>
-__global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ dy,
-                                                            const int* __restrict__ argmax, float* __restrict__ dx,
+template <typename T, int CD, int CH, int CW>
+__global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, PoolMagic q, const T* __restrict__ dy,
+                                                            const int* __restrict__ argmax, T* __restrict__ dx,
                                                             unsigned total, int accumulate) {
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= total) return;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, Poo
           const bool ok = od <= od_hi && oh <= oh_hi && ow <= ow_hi;
           const long long o = obase + (ok ? (long long)od * OHW + oh * g.OW + ow : 0);
           const int e = (a * CH + b) * CW + c;
-          okv[e] = ok; am[e] = argmax[o]; gv[e] = dy[o];
+          okv[e] = ok; am[e] = argmax[o]; gv[e] = (float)dy[o];
         }
 #pragma unroll
     for (int e = 0; e < CD * CH * CW; ++e) acc += (okv[e] && am[e] == s) ? gv[e] : 0.f;
@@ -107,38 +107,40 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, Poo
       for (int oh = oh_lo; oh <= oh_hi; ++oh)
         for (int ow = ow_lo; ow <= ow_hi; ++ow) {
           const long long o = obase + (long long)od * OHW + oh * g.OW + ow;
-          if (argmax[o] == s) acc += dy[o];
+          if (argmax[o] == s) acc += (float)dy[o];
         }
   }
-  dx[i] = accumulate ? dx[i] + acc : acc;
+  dx[i] = (T)(accumulate ? (float)dx[i] + acc : acc);
 }
 
 // y[p] = norm * sum_d wt[d] * sum_hw x[p,d,hw]; one wave per (n,c) plane.
-__global__ __launch_bounds__(256) void wavgpool_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+template <typename T>
+__global__ __launch_bounds__(256) void wavgpool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ wt,
                                                            float norm, long long NC, int D, int HW,
                                                            float* __restrict__ y) {
   const long long p = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= NC) return;
   const int lane = threadIdx.x & 63;
-  const float* xp = x + p * ((long long)D * HW);
+  const T* xp = x + p * ((long long)D * HW);
   float s = 0.f;
   for (int d = 0; d < D; ++d) {
     float t = 0.f;
-    for (int i = lane; i < HW; i += 64) t += xp[(long long)d * HW + i];
+    for (int i = lane; i < HW; i += 64) t += (float)xp[(long long)d * HW + i];
     s += (wt ? wt[d] : 1.f) * t;
   }
   s = gca_wave_sum(s);
   if (lane == 0) y[p] = s * norm;
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void wavgpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ wt,
                                                            float norm, long long total, int D, int HW,
-                                                           float* __restrict__ dx) {
+                                                           T* __restrict__ dx) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const long long p = i / ((long long)D * HW);
   const int d = (int)((i / HW) % D);
-  dx[i] = dy[p] * norm * (wt ? wt[d] : 1.f);
+  dx[i] = (T)(dy[p] * norm * (wt ? wt[d] : 1.f));
 }
 
 inline bool pool_ok(const gca_pool_geom* g) {
@@ -167,16 +169,23 @@ static PoolMagic pool_magic(const gca_pool_geom* g) {
   return q;
 }
 
-int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t* argmax, const float* scale,
-                      const float* shift, void* stream) {
+int gca_maxpool3d_fwd(const gca_pool_geom* g, const void* x, void* y, int32_t* argmax, const float* scale,
+                      const float* shift, int act_f16, void* stream) {
   if (!pool_ok(g) || !x || !y || ((scale == nullptr) != (shift == nullptr))) return GCA_EINVAL;
   const long long total = (long long)g->N * g->C * g->OD * g->OH * g->OW;
   if (total >= (1LL << 31) || (long long)g->D * g->H * g->W >= (1LL << 31)) return GCA_EINVAL;
   const PoolMagic q = pool_magic(g);
   const dim3 grid((unsigned)gca_ceil_div(total, 256));
   hipStream_t st = (hipStream_t)stream;
-#define GCA_POOL_FWD(KD, KH, KW) \
-  hipLaunchKernelGGL((maxpool3d_fwd_kernel<KD, KH, KW>), grid, dim3(256), 0, st, *g, q, x, y, argmax, (unsigned)total, scale, shift)
+#define GCA_POOL_FWD(KD, KH, KW)                                                                                              \
+  do {                                                                                                                      \
+    if (act_f16)                                                                                                            \
+      hipLaunchKernelGGL((maxpool3d_fwd_kernel<gca_half, KD, KH, KW>), grid, dim3(256), 0, st, *g, q, (const gca_half*)x,   \
+                         (gca_half*)y, argmax, (unsigned)total, scale, shift);                                              \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((maxpool3d_fwd_kernel<float, KD, KH, KW>), grid, dim3(256), 0, st, *g, q, (const float*)x,         \
+                         (float*)y, argmax, (unsigned)total, scale, shift);                                                 \
+  } while (0)
   if (g->kd == 3 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(3, 3, 3);
   else if (g->kd == 1 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(1, 3, 3);
   else if (g->kd == 2 && g->kh == 2 && g->kw == 2) GCA_POOL_FWD(2, 2, 2);
@@ -185,8 +194,8 @@ int gca_maxpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, int32_t*
   return gca_launch_status();
 }
 
-int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* argmax, float* dx,
-                      int accumulate, void* stream) {
+int gca_maxpool3d_bwd(const gca_pool_geom* g, const void* dy, const int32_t* argmax, void* dx,
+                      int accumulate, int act_f16, void* stream) {
   if (!pool_ok(g) || !dy || !argmax || !dx) return GCA_EINVAL;
   const long long total = (long long)g->N * g->C * g->D * g->H * g->W;
   if (total >= (1LL << 31)) return GCA_EINVAL;
@@ -194,9 +203,15 @@ int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* ar
   const dim3 grid((unsigned)gca_ceil_div(total, 256));
   hipStream_t st = (hipStream_t)stream;
   const int cd = (int)gca_ceil_div(g->kd, g->sd), ch = (int)gca_ceil_div(g->kh, g->sh), cw = (int)gca_ceil_div(g->kw, g->sw);
-#define GCA_POOL_BWD(CD, CH, CW) \
-  hipLaunchKernelGGL((maxpool3d_bwd_kernel<CD, CH, CW>), grid, dim3(256), 0, st, *g, q, dy, argmax, dx, (unsigned)total, \
-                     accumulate ? 1 : 0)
+#define GCA_POOL_BWD(CD, CH, CW)                                                                                             \
+  do {                                                                                                                     \
+    if (act_f16)                                                                                                           \
+      hipLaunchKernelGGL((maxpool3d_bwd_kernel<gca_half, CD, CH, CW>), grid, dim3(256), 0, st, *g, q, (const gca_half*)dy, \
+                         argmax, (gca_half*)dx, (unsigned)total, accumulate ? 1 : 0);                                      \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((maxpool3d_bwd_kernel<float, CD, CH, CW>), grid, dim3(256), 0, st, *g, q, (const float*)dy,       \
+                         argmax, (float*)dx, (unsigned)total, accumulate ? 1 : 0);                                         \
+  } while (0)
   if (cd == 2 && ch == 2 && cw == 2) GCA_POOL_BWD(2, 2, 2);
   else if (cd == 1 && ch == 2 && cw == 2) GCA_POOL_BWD(1, 2, 2);
   else if (cd == 3 && ch == 3 && cw == 3) GCA_POOL_BWD(3, 3, 3);
@@ -206,20 +221,28 @@ int gca_maxpool3d_bwd(const gca_pool_geom* g, const float* dy, const int32_t* ar
   return gca_launch_status();
 }
 
-int gca_wavgpool_fwd(const float* x, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
-                     float* y, void* stream) {
+int gca_wavgpool_fwd(const void* x, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
+                     float* y, int x_f16, void* stream) {
   if (!x || !y || NC <= 0 || D <= 0 || HW <= 0) return GCA_EINVAL;
-  hipLaunchKernelGGL(wavgpool_fwd_kernel, dim3((unsigned)gca_ceil_div(NC, 4)), dim3(256), 0, (hipStream_t)stream,
-                     x, wt, norm, (long long)NC, (int)D, (int)HW, y);
+  if (x_f16)
+    hipLaunchKernelGGL(wavgpool_fwd_kernel<gca_half>, dim3((unsigned)gca_ceil_div(NC, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const gca_half*)x, wt, norm, (long long)NC, (int)D, (int)HW, y);
+  else
+    hipLaunchKernelGGL(wavgpool_fwd_kernel<float>, dim3((unsigned)gca_ceil_div(NC, 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)x, wt, norm, (long long)NC, (int)D, (int)HW, y);
   return gca_launch_status();
 }
 
 int gca_wavgpool_bwd(const float* dy, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
-                     float* dx, void* stream) {
+                     void* dx, int x_f16, void* stream) {
   if (!dy || !dx || NC <= 0 || D <= 0 || HW <= 0) return GCA_EINVAL;
   const long long total = (long long)NC * D * HW;
-  hipLaunchKernelGGL(wavgpool_bwd_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0,
-                     (hipStream_t)stream, dy, wt, norm, total, (int)D, (int)HW, dx);
+  if (x_f16)
+    hipLaunchKernelGGL(wavgpool_bwd_kernel<gca_half>, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, wt, norm, total, (int)D, (int)HW, (gca_half*)dx);
+  else
+    hipLaunchKernelGGL(wavgpool_bwd_kernel<float>, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0,
+                       (hipStream_t)stream, dy, wt, norm, total, (int)D, (int)HW, (float*)dx);
   return gca_launch_status();
 }
 

@@ -114,7 +114,7 @@ class HipConv3d(nn.Module, _PackedWeight):
                 raise RuntimeError('conv input must be NCDHW-contiguous inside each clip')
             xs = x.stride(0)
         return ops.conv_plan(tuple(x.shape), self.out_channels, self.kernel_size, self.stride, self.padding,
-                             x.device, xs)
+                             x.device, xs, act_f16=x.dtype is torch.float16)
 
     def forward(self, x):      # plain inference use of the leaf (no BN fusion)
         return ops.conv_fwd(self.plan(x), x, self.packed(self.plan(x), 0), None if self.bias is None else self.bias.data)
@@ -185,6 +185,13 @@ def _bn_scale_shift(bn, ss, sq, count):
                            bn.running_mean, bn.running_var, bn.num_batches_tracked)
 
 
+def _stored(x):
+    """fp16-storage path (ops.set_conv_math('fp16')): the fp32 clip is cast once, where it enters the first conv."""
+    if ops.ACT_F16[0] and x.dtype is torch.float32 and x.dim() == 5:
+        return ops.cast_f16(x)
+    return x
+
+
 def f_seq(tape, module, xv):
     """Run a container: modules with their own ``fwd`` (blocks, graph-wrapped modules), max pools and
     plain nn.Sequential chains of those."""
@@ -217,7 +224,7 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
     """z = [relu]( BN(conv(x)) [+ residual] ).  Training-mode BN takes its batch statistics from the
     conv epilogue (no extra pass over y).  Follows resnet2p1d.py:66-85 / s3d_1.py:43-47,61-68.
     `out`: optional channel-slice view of a wider buffer to receive z (Inception concat)."""
-    x = xv.t
+    x = _stored(xv.t)
     plan = conv.plan(x)
     N, K, OD, OH, OW = plan.out_shape
     SP = OD * OH * OW
@@ -263,7 +270,7 @@ DEBUG_GRADS = None
 
 def f_conv(tape, conv, xv):
     """Plain convolution (optional bias), no normalisation: temporal_graph.py:46,119-122."""
-    x = xv.t
+    x = _stored(xv.t)
     plan = conv.plan(x)
     y = ops.conv_fwd(plan, x, conv.packed(plan, 0), None if conv.bias is None else conv.bias.data, w_raw=conv.weight.data)
     yv = Var(y, tape.recording)
@@ -347,7 +354,7 @@ def f_conv_bn_relu_maxpool(tape, conv, bn, pool, xv):
     """maxpool(relu(BN(conv(x)))) with the BN+ReLU evaluated inside the pooling kernel: the normalised tensor (the
     largest activation of the R(2+1)D / 3D-ResNet stems, resnet2p1d.py:252-255, resnet.py:176-179) is never written.
     Backward: pool gather -> BN backward with the ReLU mask recomputed from the conv output -> wgrad / dgrad."""
-    x = xv.t
+    x = _stored(xv.t)
     plan = conv.plan(x)
     N, K, OD, OH, OW = plan.out_shape
     SP = OD * OH * OW
@@ -405,7 +412,7 @@ def f_wavgpool(tape, xv, wt=None, norm=None):
 
     def back():
         if xv.needs_grad:
-            xv.add_grad(ops.wavgpool_bwd(yv.grad, wt, norm, tuple(x.shape)))
+            xv.add_grad(ops.wavgpool_bwd(yv.grad, wt, norm, tuple(x.shape), x.dtype))
         yv.grad = None
     tape.record(back)
     return yv

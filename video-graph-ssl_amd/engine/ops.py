@@ -11,9 +11,10 @@ import os
 import torch
 
 from .. import _hip as H
-from .._hip import ptr, stream
+from .._hip import aptr, is_half, ptr, stream
 
 F32 = torch.float32
+F16 = torch.float16
 
 
 def _t3(v):
@@ -68,17 +69,33 @@ _TUNE_PATH = os.environ.get('GCA_TUNE_CACHE', '')
 
 
 CONV_MATH = {'f32': 0, 'bf16x3': 1, 'bf16x6': 2}
+ACT_F16 = [False]
 
 
 def set_conv_math(mode):
     """Arithmetic of the conv kernels: 'f32' (fp32 MFMA), 'bf16x6' (fp32-grade split products) or 'bf16x3' (faster); see
     gca_set_conv_math in include/gca_hip.h.  Plans tuned under one mode re-tune under the other (cache keys differ),
-    but a plan object keeps the configuration it was tuned with: set the mode before building the model."""
-    H.call('gca_set_conv_math', CONV_MATH[mode])
+    but a plan object keeps the configuration it was tuned with: set the mode before building the model.
+
+    'fp16' is the fp16-STORAGE path (BASELINE configs[4]): every feature map between the input clip and the pooled
+    features, and its gradient, lives in HBM as IEEE fp16; the convs run v_mfma_f32_32x32x16_f16 with fp32 accumulation;
+    BatchNorm statistics, parameters (fp32 masters), their gradients, the head and the loss stay fp32."""
+    ACT_F16[0] = mode == 'fp16'
+    H.call('gca_set_conv_math', CONV_MATH['bf16x6' if mode == 'fp16' else mode])
 
 
 def get_conv_math():
-    return ('f32', 'bf16x3', 'bf16x6')[H.lib.gca_get_conv_math()]
+    return 'fp16' if ACT_F16[0] else ('f32', 'bf16x3', 'bf16x6')[H.lib.gca_get_conv_math()]
+
+
+def cast_f16(x):
+    """fp32 -> dense fp16 copy (the input clips of the fp16-storage path); x may be a channel slice of a wider batch."""
+    rows, re = (1, x.numel()) if x.is_contiguous() else (x.shape[0], x[0].numel())
+    if not x.is_contiguous() and not x[0].is_contiguous():
+        raise RuntimeError('only channel slices of a contiguous (N, Ctot, ...) buffer are supported')
+    y = torch.empty(x.shape, dtype=F16, device=x.device)
+    H.call('gca_cast_f16', ptr(x), rows, re, re if x.is_contiguous() else x.stride(0), aptr(y), stream())
+    return y
 
 
 def load_tune_cache(path):
@@ -118,12 +135,14 @@ class ConvPlan:
     """Everything geometry-dependent about one conv: the ABI struct, device gather tables, and the launch
     configuration pinned by a one-off measurement (the role cudnn.benchmark plays in the reference)."""
 
-    def __init__(self, N, Cin, D, Hh, W, K, k, s, p, device, x_batch_stride=0):
+    def __init__(self, N, Cin, D, Hh, W, K, k, s, p, device, x_batch_stride=0, act_f16=False):
         kd, kh, kw = _t3(k)
         sd, sh, sw = _t3(s)
         pd, ph, pw = _t3(p)
         OD, OH, OW = (D + 2 * pd - kd) // sd + 1, (Hh + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         self.g = H.ConvGeom(N, Cin, D, Hh, W, K, kd, kh, kw, sd, sh, sw, pd, ph, pw, OD, OH, OW, x_batch_stride)
+        self.g.act_f16 = int(bool(act_f16))
+        self.act_dtype = F16 if act_f16 else F32
         self.gp = C.byref(self.g)
         self.in_shape = (N, Cin, D, Hh, W)
         self.out_shape = (N, K, OD, OH, OW)
@@ -259,7 +278,7 @@ class ConvPlan:
         N, K, OD, OH, OW = self.out_shape
         key = '%d:%s' % (which, ','.join(str(int(v)) for v in (g.N, g.C, g.D, g.H, g.W, g.K, g.kd, g.kh, g.kw, g.sd, g.sh,
                                                                  g.sw, g.pd, g.ph, g.pw, g.x_batch_stride)))
-        key = 'v%d%s:%s' % (H.lib.gca_version(), ('', 'b', 'c')[H.lib.gca_get_conv_math()], key)
+        key = 'v%d%s:%s' % (H.lib.gca_version(), 'h' if g.act_f16 else ('', 'b', 'c')[H.lib.gca_get_conv_math()], key)
         hit = _TUNE_CACHE.get(key)
 
         def apply(c):
@@ -302,7 +321,7 @@ class ConvPlan:
             cands = self._wgrad_candidates(K, g.C * self.taps, -(-(N * OD * OH * OW) // 32))
         # The arithmetic mode is a floor on accuracy: a pass may run a MORE accurate kernel when that one is faster
         # (tune_*_math = 1 + arithmetic; f32 > bf16x6 > bf16x3).  0 = the mode itself.
-        maths = {0: (0,), 2: (0, 1), 1: (0, 3, 1)}[H.lib.gca_get_conv_math()]
+        maths = (0,) if g.act_f16 else {0: (0,), 2: (0, 1), 1: (0, 3, 1)}[H.lib.gca_get_conv_math()]
 
         packed_as = [layout0]
 
@@ -331,7 +350,7 @@ class ConvPlan:
                 if t is not None:
                     timed.append((t, c))
         timed.sort()
-        if which < 2 and timed:
+        if which < 2 and timed and not g.act_f16:          # (two-phase launches are built for fp32 storage only)
             # two-phase launches on the fastest single-launch shapes: tall tiles for the full waves of workgroups, short
             # tiles for the remainder (how many workgroups run at once is not known here, so a few guesses are measured)
             M, Ntot = (K, N * OD * OH * OW) if which == 0 else (g.C, g.N * g.D * g.H * g.W)
@@ -370,14 +389,14 @@ class ConvPlan:
 
 @functools.lru_cache(maxsize=None)
 def _conv_plan(N, Cin, D, Hh, W, K, k, s, p, dev_type, dev_index, xbs, math):
-    return ConvPlan(N, Cin, D, Hh, W, K, k, s, p, torch.device(dev_type, dev_index), xbs)
+    return ConvPlan(N, Cin, D, Hh, W, K, k, s, p, torch.device(dev_type, dev_index), xbs, act_f16=math == 3)
 
 
-def conv_plan(x_shape, K, k, s, p, device, x_batch_stride=0):
+def conv_plan(x_shape, K, k, s, p, device, x_batch_stride=0, act_f16=False):
     N, Cin, D, Hh, W = x_shape
-    # one plan (= one set of tuned launch configurations) per geometry AND arithmetic mode
+    # one plan (= one set of tuned launch configurations) per geometry AND arithmetic mode (3 = fp16 storage)
     return _conv_plan(N, Cin, D, Hh, W, K, _t3(k), _t3(s), _t3(p), device.type, device.index, int(x_batch_stride),
-                      H.lib.gca_get_conv_math())
+                      3 if act_f16 else H.lib.gca_get_conv_math())
 
 
 def conv_pack(plan, which, w, out=None):
@@ -388,9 +407,16 @@ def conv_pack(plan, which, w, out=None):
     return out
 
 
+def _act(plan, t):
+    """Pointer of an activation operand of a conv, checked against the storage type the plan was built for."""
+    if t.dtype is not plan.act_dtype:
+        raise TypeError('conv plan built for %s activations, got %s' % (plan.act_dtype, t.dtype))
+    return aptr(t)
+
+
 def _conv_fwd_launch(plan, x, wpack, bias, y, ss, sq):
     ws = WS.get(plan.fwd_ws, x.device) if plan.fwd_ws else None
-    H.call('gca_conv_fwd', plan.gp, ptr(x), ptr(wpack), ptr(plan.table(0)), ptr(bias), ptr(y), ptr(ss), ptr(sq),
+    H.call('gca_conv_fwd', plan.gp, _act(plan, x), ptr(wpack), ptr(plan.table(0)), ptr(bias), _act(plan, y), ptr(ss), ptr(sq),
            ptr(ws), stream())
 
 
@@ -403,7 +429,7 @@ def _repacker(plan, which, w_raw, wpack):
 def conv_fwd(plan, x, wpack, bias=None, stats=False, w_raw=None):
     """-> y [, (stat_sum, stat_sq)]  with stat layout [K][plan.parts].  w_raw: the unpacked weights behind `wpack`; lets
     the one-off launch tuning try configurations that read another packed layout (it re-packs into `wpack`)."""
-    y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    y = torch.empty(plan.out_shape, dtype=plan.act_dtype, device=x.device)
     if not plan.tuned[0]:
         plan.tune(0, lambda: _conv_fwd_launch(plan, x, wpack, bias, y, None, None), _repacker(plan, 0, w_raw, wpack))
     ss = sq = None
@@ -416,16 +442,16 @@ def conv_fwd(plan, x, wpack, bias=None, stats=False, w_raw=None):
 
 def _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate):
     ws = WS.get(plan.dgrad_ws, dy.device) if plan.dgrad_ws else None
-    H.call('gca_conv_dgrad', plan.gp, ptr(dy), ptr(wpack_t), ptr(plan.table(1)), ptr(dx), int(accumulate), ptr(ws),
+    H.call('gca_conv_dgrad', plan.gp, _act(plan, dy), ptr(wpack_t), ptr(plan.table(1)), _act(plan, dx), int(accumulate), ptr(ws),
            stream())
 
 
 def conv_dgrad(plan, dy, wpack_t, dx=None, accumulate=False, w_raw=None):
     if dx is None:
-        dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        dx = torch.empty(plan.in_shape, dtype=plan.act_dtype, device=dy.device)
         accumulate = False
     if not plan.tuned[1]:
-        scratch = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        scratch = torch.empty(plan.in_shape, dtype=plan.act_dtype, device=dy.device)
         plan.tune(1, lambda: _conv_dgrad_launch(plan, dy, wpack_t, scratch, False), _repacker(plan, 1, w_raw, wpack_t))
     _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate)
     return dx
@@ -433,7 +459,7 @@ def conv_dgrad(plan, dy, wpack_t, dx=None, accumulate=False, w_raw=None):
 
 def _conv_wgrad_launch(plan, x, dy, dw, accumulate):
     ws = WS.get(plan.wgrad_ws, x.device)
-    H.call('gca_conv_wgrad', plan.gp, ptr(x), ptr(dy), ptr(plan.table(2)), ptr(dw), int(accumulate), ptr(ws), stream())
+    H.call('gca_conv_wgrad', plan.gp, _act(plan, x), _act(plan, dy), ptr(plan.table(2)), ptr(dw), int(accumulate), ptr(ws), stream())
 
 
 def conv_wgrad(plan, x, dy, dw, accumulate=True):
@@ -453,7 +479,7 @@ def bn_stats(x, N, Cc, SP):
     P = H.lib.gca_bn_stats_parts(N, Cc, SP)
     ss = torch.empty((Cc, P), dtype=F32, device=x.device)
     sq = torch.empty((Cc, P), dtype=F32, device=x.device)
-    H.call('gca_bn_stats', ptr(x), N, Cc, SP, ptr(ss), ptr(sq), None, stream())
+    H.call('gca_bn_stats', aptr(x), N, Cc, SP, ptr(ss), ptr(sq), None, is_half(x), stream())
     return ss, sq
 
 
@@ -474,8 +500,8 @@ def bn_train_fwd(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt, x,
     st = torch.empty((4, Cc), dtype=F32, device=ss.device)
     z = torch.empty_like(x) if out is None else out
     H.call('gca_bn_train_fwd', ptr(ss), ptr(sq), P, Cc, float(count), ptr(gamma), ptr(beta), float(eps), float(momentum),
-           ptr(rmean), ptr(rvar), ptr(nbt), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(x), ptr(residual),
-           int(relu), N, SP, ptr(z), _slice_stride(z, Cc, SP), stream())
+           ptr(rmean), ptr(rvar), ptr(nbt), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), aptr(x), aptr(residual),
+           int(relu), N, SP, aptr(z), _slice_stride(z, Cc, SP), is_half(x, residual, z), stream())
     return z, st[0], st[1], st[2], st[3]
 
 
@@ -498,8 +524,8 @@ def _slice_stride(t, Cc, SP):
 
 def bn_apply(x, scale, shift, residual, relu, N, Cc, SP, out=None):
     z = torch.empty_like(x) if out is None else out
-    H.call('gca_bn_apply', ptr(x), ptr(scale), ptr(shift), ptr(residual), int(relu), N, Cc, SP, ptr(z),
-           _slice_stride(z, Cc, SP), stream())
+    H.call('gca_bn_apply', aptr(x), ptr(scale), ptr(shift), aptr(residual), int(relu), N, Cc, SP, aptr(z),
+           _slice_stride(z, Cc, SP), is_half(x, residual, z), stream())
     return z
 
 
@@ -508,9 +534,9 @@ def bn_bwd(dz, z, x, gamma, mean, invstd, relu, N, Cc, SP, dgamma, dbeta, dres=N
     """relu: False/0 none, True/1 mask from z, 2 mask recomputed from x with the forward's (scale, shift)."""
     dx = torch.empty_like(x)
     ws = WS.get(H.lib.gca_bn_bwd_ws_bytes(N, Cc, SP), x.device)
-    H.call('gca_bn_bwd', ptr(dz), ptr(z) if int(relu) == 1 else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu),
-           N, Cc, SP, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dres), int(dres_accumulate), _slice_stride(dz, Cc, SP),
-           ptr(scale), ptr(shift), ptr(ws), stream())
+    H.call('gca_bn_bwd', aptr(dz), aptr(z) if int(relu) == 1 else None, aptr(x), ptr(gamma), ptr(mean), ptr(invstd), int(relu),
+           N, Cc, SP, aptr(dx), ptr(dgamma), ptr(dbeta), aptr(dres), int(dres_accumulate), _slice_stride(dz, Cc, SP),
+           ptr(scale), ptr(shift), ptr(ws), is_half(dz, z if int(relu) == 1 else None, x, dres), stream())
     return dx
 
 
@@ -534,31 +560,31 @@ def pool_plan(x_shape, k, s, p):
 
 def maxpool_fwd(plan, x, want_argmax=True, scale=None, shift=None):
     """scale/shift: pool relu(x*scale[c]+shift[c]) (the BatchNorm+ReLU in front of the pool) without materialising it."""
-    y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    y = torch.empty(plan.out_shape, dtype=x.dtype, device=x.device)
     am = torch.empty(plan.out_shape, dtype=torch.int32, device=x.device) if want_argmax else None
-    H.call('gca_maxpool3d_fwd', plan.gp, ptr(x), ptr(y), ptr(am), ptr(scale), ptr(shift), stream())
+    H.call('gca_maxpool3d_fwd', plan.gp, aptr(x), aptr(y), ptr(am), ptr(scale), ptr(shift), is_half(x), stream())
     return y, am
 
 
 def maxpool_bwd(plan, dy, argmax, dx=None, accumulate=False):
     if dx is None:
-        dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        dx = torch.empty(plan.in_shape, dtype=dy.dtype, device=dy.device)
         accumulate = False
-    H.call('gca_maxpool3d_bwd', plan.gp, ptr(dy), ptr(argmax), ptr(dx), int(accumulate), stream())
+    H.call('gca_maxpool3d_bwd', plan.gp, aptr(dy), ptr(argmax), aptr(dx), int(accumulate), is_half(dy, dx), stream())
     return dx
 
 
 def wavgpool_fwd(x, wt, norm):
     N, Cc, D, Hh, W = x.shape
     y = torch.empty((N, Cc), dtype=F32, device=x.device)
-    H.call('gca_wavgpool_fwd', ptr(x), ptr(wt), float(norm), N * Cc, D, Hh * W, ptr(y), stream())
+    H.call('gca_wavgpool_fwd', aptr(x), ptr(wt), float(norm), N * Cc, D, Hh * W, ptr(y), is_half(x), stream())
     return y
 
 
-def wavgpool_bwd(dy, wt, norm, x_shape):
+def wavgpool_bwd(dy, wt, norm, x_shape, dtype=F32):
     N, Cc, D, Hh, W = x_shape
-    dx = torch.empty(x_shape, dtype=F32, device=dy.device)
-    H.call('gca_wavgpool_bwd', ptr(dy), ptr(wt), float(norm), N * Cc, D, Hh * W, ptr(dx), stream())
+    dx = torch.empty(x_shape, dtype=dtype, device=dy.device)
+    H.call('gca_wavgpool_bwd', ptr(dy), ptr(wt), float(norm), N * Cc, D, Hh * W, aptr(dx), is_half(dx), stream())
     return dx
 
 
@@ -735,7 +761,10 @@ def fill(t, v):
 
 
 def axpy(y, x, a=1.0):
-    H.call('gca_axpy', ptr(y), ptr(x), y.numel(), float(a), stream())
+    if is_half(y, x):
+        H.call('gca_axpy_f16', aptr(y), aptr(x), y.numel(), float(a), stream())
+    else:
+        H.call('gca_axpy', ptr(y), ptr(x), y.numel(), float(a), stream())
 
 
 def scale_(y, a):

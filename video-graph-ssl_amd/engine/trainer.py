@@ -13,6 +13,8 @@ Everything between the collectives is a fixed kernel sequence, so it is captured
 (one for N=1; three segments around the collectives for N>1) and replayed per step.
 """
 import atexit
+import math
+import os
 import weakref
 
 import torch
@@ -126,11 +128,23 @@ class _TrainerBase(object):
         return False
 
 
+def _loss_scale():
+    """Static loss scale of the fp16-storage path (a power of two: scaling and un-scaling are exact in fp32; the
+    activation gradients, stored fp16, stay clear of the subnormal range).  1 for fp32 storage."""
+    if not ops.ACT_F16[0]:
+        return 1.0
+    s = float(os.environ.get('GCA_LOSS_SCALE', '1024'))
+    if s <= 0 or math.frexp(s)[0] != 0.5:
+        raise ValueError('GCA_LOSS_SCALE must be a positive power of two, got %r' % s)
+    return s
+
+
 class MoCoTrainer(_TrainerBase):
     def __init__(self, cfg, device, ctx=None, use_graph=True, seed=None):
         _check_unsupported(cfg)
         self.cfg, self.device = cfg, torch.device(device)
         self.clip = clip_value_of(cfg)
+        self.loss_scale = _loss_scale()
         self.ctx = ctx or par.DistCtx()
         if seed is not None:
             torch.manual_seed(seed)
@@ -218,7 +232,7 @@ class MoCoTrainer(_TrainerBase):
         saved = ops.queue_enqueue(mem, s['all_k'], 0, save=True, ptr_dev=self.ptr_dev)
         # DDP averages gradients: fold 1/world into the loss-gradient scale
         qv.grad = ops.moco_logits_bwd(s['k'], mem, self.inv_T, logits=logits, lse=lse,
-                                      gscale_host=1.0 / self.ctx.world, ov_rows=saved, ov_start_dev=self.ptr_dev)
+                                      gscale_host=self.loss_scale / self.ctx.world, ov_rows=saved, ov_start_dev=self.ptr_dev)
         ops.queue_advance(self.ptr_dev, s['all_k'].shape[0], self.K)
         self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
         tape.backward(upto)
@@ -234,6 +248,8 @@ class MoCoTrainer(_TrainerBase):
 
     def _phase_update(self):
         clip = None
+        if self.loss_scale != 1.0:                                            # fp16 storage: gradients were computed x S
+            ops.scale_(self.arena_q.grad, 1.0 / self.loss_scale)
         if self.clip is not None:                                             # :420-423, after the gradient all-reduce
             clip = self.optimizer.clip_grad_norm(self.clip)
             self.out['grad_norm'] = clip
