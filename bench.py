@@ -209,8 +209,6 @@ def kernel_timing(pkg, trainer, args):
                   launches_per_step=sym[dom][2], flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1),
                   algorithmic_bytes_per_launch_avg=round(sym[dom][3] / sym[dom][2], 1))
     nprod = {0: 1, 1: 3, 2: 6, 3: 1}[_MATH[0]]
-    if _MATH[0] == 3 and ',true>' in dom:
-        nprod = 3                  # the fp16-storage gather kernels multiply as bf16x3 (an fp16 value is exactly hi + lo)
     if _MATH[0] == 0:
         roof = dict(bound='mfma', achieved=ach, peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
                     frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common)

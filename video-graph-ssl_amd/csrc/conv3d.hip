@@ -52,7 +52,7 @@ namespace {
 constexpr int LDK = BK + 4;     // LDS row pitch in floats (80 B)
 // pitch by arithmetic mode: a row of 16 k is 64 B as fp32 or as bf16 hi+lo pairs, 96 B as bf16 hi+mid+lo (+16 B pad each:
 // 20 r mod 64 and 28 r mod 64 both walk all 16 four-bank groups over 16 rows, so the b128 fragment reads are conflict-free)
-constexpr int lds_pitch(int math) { return math == 2 ? 28 : LDK; }
+constexpr int lds_pitch(int math) { return math == 2 ? 28 : (math == 3 ? 12 : LDK); }   // (3: 32-byte rows of halves + 16 B: 3 r mod 8 walks all eight 16-byte bank groups)
 // LDS buffers of the k-loop: the tall / 256-column bf16x6 tiles (96-byte rows) keep ONE (the next tile waits in registers
 // anyway; a second barrier per k-tile) so that 3-5 workgroups stay resident per CU instead of 2 and one workgroup's
 // split/store phase overlaps another's MFMAs
@@ -114,12 +114,19 @@ __device__ __forceinline__ void igemm_tile(
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, p.src_bytes, 0x00020000);
   const unsigned cb4 = (unsigned)colbase * ES;
   // one gathered element / four consecutive ones at byte offset `voff` of the source, as fp32
+  // (MATH 3: the half is NOT widened -- its 16 bits travel in the low half of the "float" until they are packed into LDS)
   auto ld1 = [&](unsigned voff) __attribute__((always_inline)) {
-    if constexpr (H) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
+    if constexpr (H && MATH == 3) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
+    else if constexpr (H) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
     else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
   };
   auto ld4 = [&](unsigned voff) __attribute__((always_inline)) {
-    if constexpr (H) {
+    if constexpr (H && MATH == 3) {
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0));
+      const unsigned ux = u.x, uy = u.y;
+      return make_float4(__uint_as_float(ux & 0xffffu), __uint_as_float(ux >> 16), __uint_as_float(uy & 0xffffu), __uint_as_float(uy >> 16));
+    } else if constexpr (H) {
       typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
       typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
       const f16x4_t hv = __builtin_bit_cast(f16x4_t, __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0)));
@@ -228,9 +235,20 @@ __device__ __forceinline__ void igemm_tile(
   // MATH >= 1: every fp32 operand x is stored as bf16 parts -- bf16x3: hi = bf16(x), lo = bf16(x - hi); bf16x6: hi, mid, lo
   // (x = hi + mid + lo to 2^-27).  A row of 16 k is two 8-k groups [hi x8 | (mid x8 |) lo x8]: the 16-byte operands that a
   // lane of half h feeds to v_mfma_f32_32x32x16_bf16 sit at float index 4*NP*h + {0, 4, (8)} of the row.
-  auto store_split4 = [&](float* row, int chunk, float4 v) __attribute__((always_inline)) {     // k = 4*chunk .. +3 of `row`
+  auto store_split4 = [&](float* row, int chunk, float4 v, bool raw = false) __attribute__((always_inline)) {     // k = 4*chunk .. +3 of `row`
     float* d = row + (chunk >> 1) * (4 * NP) + (chunk & 1) * 2;
-    if (MATH == 2) {
+    if constexpr (MATH == 3) {      // fp16 operands: weights (fp32, raw = false) are rounded here; gathered halves (raw) are packed
+      uint2 o;
+      if (raw) {
+        o.x = __float_as_uint(v.x) | (__float_as_uint(v.y) << 16);
+        o.y = __float_as_uint(v.z) | (__float_as_uint(v.w) << 16);
+      } else {
+        const f16x2 lo = {(_Float16)v.x, (_Float16)v.y}, hi = {(_Float16)v.z, (_Float16)v.w};
+        o.x = __builtin_bit_cast(unsigned, lo);
+        o.y = __builtin_bit_cast(unsigned, hi);
+      }
+      *reinterpret_cast<uint2*>(d) = o;
+    } else if (MATH == 2) {
       uint2 h, m, l;
       split_bf16x3(v.x, v.y, h.x, m.x, l.x);
       split_bf16x3(v.z, v.w, h.y, m.y, l.y);
@@ -251,15 +269,18 @@ __device__ __forceinline__ void igemm_tile(
       if (A_F4 == 2 ? a_last_ok : A_F4 > 2) store_split4(&As[buf][a_slot(1) >> 2][0], a_slot(1) & 3, a1);
       if (A_F4 > 2 && a_last_ok) store_split4(&As[buf][a_slot(2) >> 2][0], a_slot(2) & 3, a2);
       if (VEC) {
-        store_split4(&Bs[buf][col + 0][0], wn, make_float4(bvec[0].x, bvec[1].x, bvec[2].x, bvec[3].x));
-        store_split4(&Bs[buf][col + 1][0], wn, make_float4(bvec[0].y, bvec[1].y, bvec[2].y, bvec[3].y));
-        store_split4(&Bs[buf][col + 2][0], wn, make_float4(bvec[0].z, bvec[1].z, bvec[2].z, bvec[3].z));
-        store_split4(&Bs[buf][col + 3][0], wn, make_float4(bvec[0].w, bvec[1].w, bvec[2].w, bvec[3].w));
+        store_split4(&Bs[buf][col + 0][0], wn, make_float4(bvec[0].x, bvec[1].x, bvec[2].x, bvec[3].x), true);
+        store_split4(&Bs[buf][col + 1][0], wn, make_float4(bvec[0].y, bvec[1].y, bvec[2].y, bvec[3].y), true);
+        store_split4(&Bs[buf][col + 2][0], wn, make_float4(bvec[0].z, bvec[1].z, bvec[2].z, bvec[3].z), true);
+        store_split4(&Bs[buf][col + 3][0], wn, make_float4(bvec[0].w, bvec[1].w, bvec[2].w, bvec[3].w), true);
       } else {          // 8 consecutive k of one column = one whole group: b128 per part
         float* d = &Bs[buf][col][(r0 >> 3) * (4 * NP)];
         constexpr int I1 = VEC ? 0 : 1, I2 = VEC ? 0 : 2, I3 = VEC ? 0 : 3, I4 = VEC ? 0 : 4, I5 = VEC ? 0 : 5,
                       I6 = VEC ? 0 : 6, I7 = VEC ? 0 : 7;
-        if (MATH == 2) {
+        if constexpr (MATH == 3) {
+          auto u = [&](int i) __attribute__((always_inline)) { return __float_as_uint(breg[i]); };
+          *reinterpret_cast<uint4*>(d) = make_uint4(u(0) | (u(I1) << 16), u(I2) | (u(I3) << 16), u(I4) | (u(I5) << 16), u(I6) | (u(I7) << 16));
+        } else if (MATH == 2) {
           uint4 h, m, l;
           split_bf16x3(breg[0], breg[I1], h.x, m.x, l.x);
           split_bf16x3(breg[I2], breg[I3], h.y, m.y, l.y);
@@ -428,6 +449,9 @@ __device__ __forceinline__ void igemm_tile(
           }
   #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            if constexpr (MATH == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, afc[0]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+            } else {
             const bf16x8 xh = __builtin_bit_cast(bf16x8, afc[0]), xl = __builtin_bit_cast(bf16x8, afc[NP - 1]);
             const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
             if (MATH == 2) {
@@ -442,6 +466,7 @@ __device__ __forceinline__ void igemm_tile(
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
             }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             f_piece(Fnew, i * TN + j, ktn);
             __builtin_amdgcn_sched_barrier(0);
@@ -481,6 +506,9 @@ __device__ __forceinline__ void igemm_tile(
         for (int i = 0; i < TM; ++i)
   #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            if constexpr (MATH == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+            } else {
             const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
             const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
             if (MATH == 2) {
@@ -495,6 +523,7 @@ __device__ __forceinline__ void igemm_tile(
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
             }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more) issue_piece(i * TN + j, kt + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -958,7 +987,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
     if (fbm & 2048) { fbm = 0; fs = 0; tail = 0; }       // not runnable as asked: fall back to the gather kernels' heuristic
   }
   IgemmCfg cf = choose_cfg(p.DK, p.Ntot, p.Kpad / BK, c.vec, fbm, fs);
-  cf.math = math == 3 ? 1 : math;
+  cf.math = math;
   cf.h = math == 3;
   if (cf.h) tail = 0;                                    // (the two-phase launch is built for fp32 storage only)
   // Two-phase launch (measured configurations only; single-class passes, 128-column tiles, no split-K): the first
@@ -981,7 +1010,7 @@ template <int TM, int BN, int FAST, bool VEC>
 void launch_one(int math, dim3 grid, hipStream_t st, const float* src, const float* apack, const int2* table, const float* bias,
                 float* dst, float* psum, float* psq, float* slab, const IgemmParams& p, bool h = false) {
   if (h)
-    hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 1, true>), grid, dim3(256), 0, st, src, apack, table, bias,
+    hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 3, true>), grid, dim3(256), 0, st, src, apack, table, bias,
                        dst, psum, psq, slab, p);
   else if (math == 1)
     hipLaunchKernelGGL((conv_igemm_kernel<TM, BN, FAST, VEC, 1>), grid, dim3(256), 0, st, src, apack, table, bias,

@@ -32,7 +32,6 @@ constexpr int PPAD = 128 * HR;        // staging tasks per channel half (tasks b
 constexpr int rowb(int math) { return math == 3 ? 32 : (math == 2 ? 96 : 64); }   // bytes of one 16-k row: fp16 / fp32 / hi+lo / hi+mid+lo
 constexpr int pitchb(int math) { return rowb(math) + 16; }            // 48 / 80 / 112 B: odd number of 16-B slots -> conflict-free b128 reads
 constexpr int nparts(int math) { return (math == 0 || math == 3) ? 1 : (math == 2 ? 3 : 2); }
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned short f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
 __device__ __forceinline__ float f16_val(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
 

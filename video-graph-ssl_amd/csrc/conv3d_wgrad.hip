@@ -60,8 +60,8 @@ __device__ __forceinline__ MaskT tap_valid_mask(const WgradParams& p, int id0, i
 // BVEC (pointwise-in-space convs: kh = kw = 1, unit spatial stride, no spatial padding): a table row's 4
 // consecutive positions are 4 consecutive floats of X, so the gather uses float4 loads too (and shares the
 // position arithmetic with the dY loads).
-// H: fp16 storage of x and dy (gca_set_conv_math(3)): elements are widened on load, the arithmetic (MATH) is unchanged --
-// an fp16 value is exactly hi + lo in the bf16x3 split; dW is accumulated and written in fp32.
+// H: fp16 storage of x and dy (gca_conv_geom.act_f16), always with MATH 3: the stored halves are the operands of
+// v_mfma_f32_32x32x16_f16 as they are (no widening, no split); dW is accumulated and written in fp32.
 template <int WM, int WN, int TM, int TN, bool AVEC, int FAST, bool BVEC, int MATH, bool H = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(
     const void* __restrict__ x, const void* __restrict__ dy, const int2* __restrict__ table,
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
 
   // row pitch: 32 k = 128 B as fp32 or bf16 hi+lo, 192 B as bf16 hi+mid+lo; +16 B pad (36 r and 52 r mod 64 both walk all
   // 16 four-bank groups over 16 rows: conflict-free b128 fragment reads)
-  constexpr int LDP = MATH == 2 ? 52 : LDW, NP = math_parts(MATH);
+  constexpr int LDP = MATH == 2 ? 52 : (MATH == 3 ? 20 : LDW), NP = math_parts(MATH);   // (3: 64-byte rows of halves + 16 B)
   // ONE LDS buffer for everything but the smallest fp32 tiles: the next tile waits in registers anyway, so the price is a
   // second barrier per k-tile, and the 75-120 KB double-buffered tiles become 38-60 KB -- two (or more) workgroups per CU,
   // so that one's load/split/store phase overlaps the other's MFMAs
@@ -105,11 +105,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dy), 0, p.dy_bytes, 0x00020000);
   auto ld1 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff) __attribute__((always_inline)) {
-    if constexpr (H) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
+    // (MATH 3: the half is not widened; its 16 bits travel in the low half of the "float" until they are packed into LDS)
+    if constexpr (H && MATH == 3) return __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
+    else if constexpr (H) return (float)__builtin_bit_cast(_Float16, (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)voff, 0, 0));
     else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, 0, 0));
   };
   auto ld4 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned voff) __attribute__((always_inline)) {
-    if constexpr (H) {
+    if constexpr (H && MATH == 3) {
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t u = __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0));
+      const unsigned ux = u.x, uy = u.y;
+      return make_float4(__uint_as_float(ux & 0xffffu), __uint_as_float(ux >> 16), __uint_as_float(uy & 0xffffu), __uint_as_float(uy >> 16));
+    } else if constexpr (H) {
       typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
       typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
       const f16x4_t hv = __builtin_bit_cast(f16x4_t, __builtin_bit_cast(u32x2_t, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0)));
@@ -233,7 +240,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   // operands of MFMA step t for a lane of half h sit at float index 4*NP*(2t + h) + {0, 4, (8)}.
   auto store_split4 = [&](float* row, int chunk, float4 v) __attribute__((always_inline)) {     // k = 4*chunk .. +3
     float* d = row + (chunk >> 1) * (4 * NP) + (chunk & 1) * 2;
-    if (MATH == 2) {
+    if constexpr (MATH == 3) {           // both operands are stored halves: pack the raw bits
+      *reinterpret_cast<uint2*>(d) = make_uint2(__float_as_uint(v.x) | (__float_as_uint(v.y) << 16),
+                                                __float_as_uint(v.z) | (__float_as_uint(v.w) << 16));
+    } else if (MATH == 2) {
       uint2 h, m, l;
       split_bf16x3(v.x, v.y, h.x, m.x, l.x);
       split_bf16x3(v.z, v.w, h.y, m.y, l.y);
@@ -250,7 +260,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
   };
   auto store_split1 = [&](float* row, int k, float v) __attribute__((always_inline)) {
     unsigned short* d = reinterpret_cast<unsigned short*>(row) + (k >> 3) * (8 * NP) + (k & 7);
-    if (MATH == 2) {
+    if constexpr (MATH == 3) {
+      d[0] = (unsigned short)__float_as_uint(v);
+    } else if (MATH == 2) {
       unsigned h, m, l;
       split_bf16x3(v, 0.f, h, m, l);
       d[0] = (unsigned short)h; d[8] = (unsigned short)m; d[16] = (unsigned short)l;
@@ -350,6 +362,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            if constexpr (MATH == 3) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[j][0]), acc[i][j], 0, 0, 0);
+            } else {
             const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
             const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[j][0]), yl = __builtin_bit_cast(bf16x8, bf[j][NP - 1]);
             if (MATH == 2) {
@@ -364,6 +379,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i][j], 0, 0, 0);
             }
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (more) issue_piece((t * TM + i) * TN + j, kt + 1);
             __builtin_amdgcn_sched_barrier(0);
@@ -554,7 +570,6 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   p.splits = (int)gca_ceil_div(p.kt_total, p.kt_per_split);
   p.math = resolve_math(g->tune_wgrad_math, g->act_f16);
   p.half = p.math == 3;
-  if (p.half) p.math = 1;                     // fp16 operands multiplied as exact bf16 hi + lo pairs
   p.chk = ((g->pd > 0 || (g->OD - 1) * g->sd + g->kd > g->D) ? 1 : 0) |
           ((g->ph > 0 || (g->OH - 1) * g->sh + g->kh > g->H) ? 2 : 0) |
           ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
@@ -574,9 +589,9 @@ void launch_w(int avec, dim3 grid, hipStream_t st, const float* x, const float* 
               const WgradParams& p) {
   if (p.half) {
     if (avec == 2 && FAST == 1)
-      hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, 1, true, 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
-    else if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST, false, 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST, false, 1, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+      hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, 1, true, 3, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+    else if (avec) hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, true, FAST, false, 3, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<WM, WN, TM, TN, false, FAST, false, 3, true>), grid, dim3(256), 0, st, x, dy, t, slab, p);
   } else if (p.math == 1) launch_wm<WM, WN, TM, TN, FAST, 1>(avec, grid, st, x, dy, t, slab, p);
   else if (p.math == 2) launch_wm<WM, WN, TM, TN, FAST, 2>(avec, grid, st, x, dy, t, slab, p);
   else launch_wm<WM, WN, TM, TN, FAST, 0>(avec, grid, st, x, dy, t, slab, p);

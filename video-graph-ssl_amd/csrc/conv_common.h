@@ -8,6 +8,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace gca_conv {
 
@@ -15,11 +17,11 @@ namespace gca_conv {
 // fp32 operands split in the kernel into 2 / 3 bf16 parts, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 // Defined in conv3d.hip (gca_set_conv_math / GCA_CONV_MATH).
 int conv_math();
-constexpr int math_parts(int math) { return math == 2 ? 3 : 2; }   // (mode 3 never reaches the gather kernels: they run it as 1)   // bf16 parts per fp32 operand element
+constexpr int math_parts(int math) { return math == 2 ? 3 : (math == 3 ? 1 : 2); }   // 16-bit parts per operand element (3 = fp16 storage: the element itself)
 // arithmetic of one pass: the tune_*_math override (1 + m) when m is at least as accurate as the mode in force
 inline int math_rank(int m) { return m == 0 ? 2 : m == 2 ? 1 : 0; }     // f32 > bf16x6 > bf16x3
-// act_f16: the activations of this convolution are fp16 in HBM (gca_conv_geom.act_f16) -> arithmetic 3: the f16 MFMA in
-// the LDS-halo kernels, exact bf16 hi + lo pairs of the widened operands in the gather / wgrad kernels; nothing to pin
+// act_f16: the activations of this convolution are fp16 in HBM (gca_conv_geom.act_f16) -> arithmetic 3: v_mfma_f32_32x32x16_f16
+// on the stored halves and on the weights rounded to fp16 (RNE) where they become an MFMA operand; nothing to pin
 inline int resolve_math(int tune_math, int act_f16 = 0) {
   const int mode = conv_math();
   if (act_f16) return 3;

@@ -101,7 +101,8 @@ def _check_unsupported(cfg):
                                   'select the reduced-precision conv path with engine.ops.set_conv_math instead')
 
 
-BUCKET_ELEMS = 8 << 20        # gradient all-reduce bucket: 8 M fp32 = 32 MB (four buckets for R(2+1)D-18 + head)
+# gradient all-reduce bucket: 8 M fp32 = 32 MB (four buckets for R(2+1)D-18 + head); 0 = one all-reduce after the backward pass
+BUCKET_ELEMS = int(os.environ.get('GCA_BUCKET_ELEMS', 8 << 20))
 
 
 class _TrainerBase(object):
@@ -312,7 +313,8 @@ class MoCoTrainer(_TrainerBase):
             s['all_k'].copy_(par.gather_keys(s['k_shuf'], self.ctx))
             s['k'].copy_(ops.gather_rows(s['all_k'], plan['unshuffle_idx']))
             bk = self._buckets
-            planning = len(bk) == 1 and not self._planned and self.arena_q.total > int(getattr(self, 'bucket_elems', BUCKET_ELEMS))
+            be = int(getattr(self, 'bucket_elems', BUCKET_ELEMS))
+            planning = len(bk) == 1 and not self._planned and 0 < be < self.arena_q.total
             if planning:
                 self._planned = True
                 L.GRAD_LOG = []
