@@ -278,8 +278,10 @@ __device__ __forceinline__ void igemm_tile(
         constexpr int I1 = VEC ? 0 : 1, I2 = VEC ? 0 : 2, I3 = VEC ? 0 : 3, I4 = VEC ? 0 : 4, I5 = VEC ? 0 : 5,
                       I6 = VEC ? 0 : 6, I7 = VEC ? 0 : 7;
         if constexpr (MATH == 3) {
-          auto u = [&](int i) __attribute__((always_inline)) { return __float_as_uint(breg[i]); };
-          *reinterpret_cast<uint4*>(d) = make_uint4(u(0) | (u(I1) << 16), u(I2) | (u(I3) << 16), u(I4) | (u(I5) << 16), u(I6) | (u(I7) << 16));
+          *reinterpret_cast<uint4*>(d) = make_uint4(__float_as_uint(breg[0]) | (__float_as_uint(breg[I1]) << 16),
+                                                    __float_as_uint(breg[I2]) | (__float_as_uint(breg[I3]) << 16),
+                                                    __float_as_uint(breg[I4]) | (__float_as_uint(breg[I5]) << 16),
+                                                    __float_as_uint(breg[I6]) | (__float_as_uint(breg[I7]) << 16));
         } else if (MATH == 2) {
           uint4 h, m, l;
           split_bf16x3(breg[0], breg[I1], h.x, m.x, l.x);
