@@ -254,6 +254,20 @@ def pmc_traffic(symbol):
     return None
 
 
+def pmc_hbm(prefix):
+    """HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE) of a head kernel from the committed PMC passes of tools/pmc_hbm.sh
+    (profiles/r02_pmc_hbm_kernels.json: the same buffer rotation as the timings below); None if not profiled."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_pmc_hbm_kernels.json')
+    try:
+        with open(path) as f:
+            for k, v in json.load(f).items():
+                if k.startswith(prefix):
+                    return v['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def infonce_timing(pkg, b=32, warm=False):
     """InfoNCE forward (logits + row log-sum-exp + top-k rank + loss) at BASELINE's two queue sizes.  The call rotates over
     enough DISTINCT queue / logits buffers that one lap exceeds the 256 MB Infinity Cache (MI355X_MICROARCH.md: scale past
@@ -278,7 +292,8 @@ def infonce_timing(pkg, b=32, warm=False):
         out['K%d' % K] = dict(ms=round(ms, 5), algorithmic_MB=round(bytes_alg / 1e6, 2), distinct_buffer_sets=nset,
                               working_set_MB=round(nset * bytes_alg / 1e6, 1),
                               GBps=round(bytes_alg / 1e9 / (ms / 1e3), 1),
-                              hbm_frac=round(bytes_alg / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4))
+                              hbm_frac=round(bytes_alg / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4),
+                              traffic=pmc_hbm('moco_logits_persist_kernel<4> grid=%d' % (8192 if K == 4096 else 65536)) if b == 32 else None)
         del mems, lgs, g
     return out
 
@@ -348,7 +363,7 @@ def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
            'final_loss': round(loss, 5),
            'step_tflops_algorithmic': round(6 * (35.958 if size == 224 else 8.949) * bsz / 1e3 / (dt / args.steps), 3),
            'roofline': dict(bound='hbm', kernel='tmix_kernel<8> (graph message passing, 8-node clip graph)', achieved=gt['GBps'],
-                            peak=PEAK_HBM_GBPS, unit='GB/s', frac=gt['hbm_frac'], traffic=None, avg_launch_ms=gt['ms'],
+                            peak=PEAK_HBM_GBPS, unit='GB/s', frac=gt['hbm_frac'], traffic=pmc_hbm('tmix_kernel<8>') if (bsz, size) == (4, 224) else None, avg_launch_ms=gt['ms'],
                             algorithmic_MB=gt['algorithmic_MB']),
            'graph_mix_fwd': gt}
     print(json.dumps(res))
