@@ -44,6 +44,7 @@ CONV_CASES = [
     ((3, 40, 3, 9, 11), 50, (3, 3, 3), (1, 1, 1), (1, 1, 1)),          # ragged tiles, channel tails
     ((2, 24, 5, 10, 10), 36, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ((4, 64, 1, 1, 1), 24, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    ((2, 3, 8, 64, 64), 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),           # large enough for the stem kernel (conv3d_stem.hip)
 ]
 
 

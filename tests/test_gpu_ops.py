@@ -236,6 +236,44 @@ def test_conv_halo_kernels_every_configuration(ops, ctol, shape, K, k, s, p):
         assert rel_err(yv, want) < ctol, ('view', view)
 
 
+@pytest.mark.parametrize('shape,K,k,s,p,bias', [
+    ((4, 3, 8, 56, 56), 45, (1, 7, 7), (1, 2, 2), (0, 3, 3), False),     # R(2+1)D / S3D stem (resnet2p1d.py:162, s3d_1.py:35)
+    ((2, 3, 8, 48, 48), 64, (7, 7, 7), (1, 2, 2), (3, 3, 3), False),     # 3D-ResNet stem (resnet.py:120)
+    ((4, 3, 5, 37, 45), 20, (3, 5, 5), (2, 1, 2), (1, 2, 2), True),      # ragged boxes, 5 taps along W, unit stride in H, bias
+    ((6, 4, 6, 30, 34), 70, (1, 3, 8), (1, 2, 2), (0, 1, 3), False),     # 4 channels, 8 W taps (no pad tap), two row tiles
+    ((4, 1, 6, 33, 64), 33, (2, 2, 2), (1, 2, 2), (0, 0, 0), False),     # one channel, even kernel, no padding
+])
+def test_conv_stem_kernel_vs_gather_and_aten(ops, ctol, shape, K, k, s, p, bias):
+    """conv3d_stem.hip (phase-split LDS halo, C <= 4, stride-2 W windows) against ATen and against the gather kernels on the
+    same operands, BatchNorm partial sums included; the f32 mode has no stem kernel and must stay on the gather kernels."""
+    torch.manual_seed(7)
+    x = torch.randn(shape)
+    w = torch.randn((K, shape[1]) + tuple(k)) * 0.1
+    b = torch.randn(K) if bias else None
+    yr = F.conv3d(x.double(), w.double(), None if b is None else b.double(), s, p)
+    plan = ops.ConvPlan(*shape, K, k, s, p, torch.device(DEV))
+    plan.tuned = [True, True, True]
+    xd, wd = x.to(DEV), w.to(DEV)
+    bd = None if b is None else b.to(DEV)
+    outs = {}
+    for name, code in (('default', 0), ('stem', 4096 | 64), ('gather', 64)):
+        plan.g.tune_fwd_bm = code
+        plan.refresh()
+        stem = (plan.cfg(0)[3] >> 16) & 1
+        assert stem == (0 if name == 'gather' or ops.get_conv_math() == 'f32' else 1), (name, stem)
+        y, (ss, sq) = ops.conv_fwd(plan, xd, ops.conv_pack(plan, 0, wd), bd, stats=True)
+        assert ss.shape[1] == plan.parts
+        outs[name] = (y, ss.sum(1), sq.sum(1))
+        assert rel_err(y, yr) < ctol, name
+    plan.g.tune_fwd_bm = 0
+    plan.refresh()
+    y0 = F.conv3d(x.double(), w.double(), None, s, p)          # statistics are those of the conv output proper (no bias)
+    for name in ('default', 'stem'):
+        assert rel_err(outs[name][0], outs['gather'][0]) < ctol
+        assert rel_err(outs[name][1], y0.sum((0, 2, 3, 4))) < 1e-4 * max(1.0, float(y0.abs().sum((0, 2, 3, 4)).max() / y0.sum((0, 2, 3, 4)).abs().max()))
+        assert rel_err(outs[name][2], (y0 * y0).sum((0, 2, 3, 4))) < 1e-4
+
+
 @pytest.mark.parametrize('shape,K,k,s,p', [
     ((2, 3, 2, 20, 20), 40, (1, 7, 7), (1, 2, 2), (0, 3, 3)),       # 49 taps: 64-bit tap mask (the R(2+1)D stem)
     ((1, 2, 9, 9, 9), 5, (7, 7, 7), (1, 2, 2), (3, 3, 3)),          # 343 taps: per-element window tests (3D-ResNet stem)

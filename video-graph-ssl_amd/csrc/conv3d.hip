@@ -774,7 +774,7 @@ __device__ __forceinline__ void pack_elements(const float* __restrict__ w, float
   }
 }
 __global__ void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ packed, PackParams p) {
-  if (p.fmt == 1)
+  if (p.fmt >= 1)
     pack_halo_elements(w, reinterpret_cast<unsigned char*>(packed), p, (long long)blockIdx.x * blockDim.x + threadIdx.x,
                        (long long)gridDim.x * blockDim.x, pack_items(p));
   else
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void conv_pack_batched_kernel(const unsigned c
   long long end = base + PACK_CHUNK;
   const long long total = pack_items(p);
   if (end > total) end = total;
-  if (p.fmt == 1) pack_halo_elements(j->w, reinterpret_cast<unsigned char*>(j->packed), p, base + threadIdx.x, 256, end);
+  if (p.fmt >= 1) pack_halo_elements(j->w, reinterpret_cast<unsigned char*>(j->packed), p, base + threadIdx.x, 256, end);
   else pack_elements(j->w, j->packed, p, base + threadIdx.x, 256, end);
 }
 
@@ -883,6 +883,58 @@ inline bool halo_heuristic_on() {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// ---- stem kernels (conv3d_stem.hip): forward class, <= 4 input channels, stride 2 and <= 8 taps along W ---------------------
+// GCA_STEM=0 keeps un-tuned stems on the gather kernels (A/B runs; the forced tune code 4096 is still honoured)
+inline bool stem_heuristic_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GCA_STEM"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+// Fills sp (box = the 128-position tiling with the least staging work per output that fits two workgroups per CU, or one if
+// none does); false when the conv cannot run there.
+inline bool stem_geometry(const gca_conv_geom* g, const IgemmParams& p, int math, StemParams& sp) {
+  if (math < 1 || math > 3 || g->C > 4 || g->sw != 2 || g->kw > 8 || g->x_batch_stride % 4 != 0) return false;
+  if ((long long)g->N * g->OD * g->OH * g->OW < 128 * 64) return false;          // not worth a halo
+  const int np = math == 3 ? 1 : (math == 2 ? 3 : 2);
+  const int pitch = (math == 3 ? 32 : (math == 2 ? 96 : 64)) + 16;
+  const int nrows = g->C * g->kd * g->kh, nsteps = cdiv(nrows, 2);
+  const int rowoff_bytes = (int)gca_round_up(2 * nsteps * 4, 16);
+  double best = 1e300;
+  int bb[3] = {0, 0, 0};
+  for (int pass = 0; pass < 2 && bb[0] == 0; ++pass) {
+    const size_t cap = pass == 0 ? (size_t)(76 << 10) : (size_t)(156 << 10);
+    for (int bd = 1; bd <= 128; bd *= 2)
+      for (int bh = 1; bd * bh <= 128; bh *= 2) {
+        const int bw = 128 / (bd * bh);
+        if (bw < 4 || bw > 64) continue;
+        if (bd > 2 * g->OD || bh > 2 * g->OH || bw > 2 * g->OW) continue;
+        const int hd = (bd - 1) * g->sd + g->kd, hh = (bh - 1) * g->sh + g->kh, wp = bw + 4;
+        const size_t lds = (size_t)rowoff_bytes + 2 * 64 * pitch + (size_t)g->C * hd * hh * 4 * np * wp * 2;
+        if (lds > cap) continue;
+        const double cover = (double)cdiv(g->OD, bd) * bd / g->OD * cdiv(g->OH, bh) * bh / g->OH * cdiv(g->OW, bw) * bw / g->OW;
+        const double staging = (double)g->C * hd * hh * 2 * wp / 128.0;           // staged elements per output position
+        const double cost = cover * (1.0 + staging / (double)(nsteps * 8)) * (bw >= 8 ? 1.0 : 1.15);
+        if (cost < best) { best = cost; bb[0] = bd; bb[1] = bh; bb[2] = bw; }
+      }
+  }
+  if (bb[0] == 0) return false;
+  sp.g = p;
+  sp.bd = bb[0]; sp.bh = bb[1]; sp.bw = bb[2]; sp.lbh = ilog2(bb[1]); sp.lbw = ilog2(bb[2]);
+  sp.nbd = cdiv(g->OD, sp.bd); sp.nbh = cdiv(g->OH, sp.bh); sp.nbw = cdiv(g->OW, sp.bw);
+  sp.hd = (sp.bd - 1) * g->sd + g->kd; sp.hh = (sp.bh - 1) * g->sh + g->kh; sp.wp = sp.bw + 4;
+  sp.sd = g->sd; sp.sh = g->sh; sp.pd = g->pd; sp.ph = g->ph; sp.pw = g->pw;
+  sp.kd = g->kd; sp.kh = g->kh; sp.kw = g->kw;
+  sp.nrows = nrows; sp.nsteps = nsteps;
+  sp.Mrows = pack_rows(g->K);
+  sp.rowoff_bytes = rowoff_bytes;
+  sp.cs_bytes = (unsigned)((long long)g->D * g->H * g->W * (g->act_f16 ? 2 : 4));
+  const long long pb = (long long)nsteps * sp.Mrows * (math == 3 ? 32 : (math == 2 ? 96 : 64));
+  sp.pack_bytes = pb > 0xfffff000LL ? 0xfffff000u : (unsigned)pb;
+  sp.m_w2 = gca_make_magic((unsigned)(2 * sp.wp)); sp.m_hdh = gca_make_magic((unsigned)(sp.hd * sp.hh));
+  sp.m_hh = gca_make_magic((unsigned)sp.hh);
+  return true;
+}
+
 // halo geometry of class c tiled by boxes (bd, bh, bw); false when the class / box cannot run on the halo kernels
 inline bool halo_geometry(const ClassInfo& c, const IgemmParams& p, int bd, int bh, int bw, int math, HaloParams& hp) {
   if (c.ntaps < 1 || c.ntaps > 64 || c.srcC < 8) return false;
@@ -942,12 +994,19 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
   int fbm, fs, tail, box;
   tune_of(g, which, fbm, fs, tail, box);
   const int math = resolve_math(which == 0 ? g->tune_fwd_math : g->tune_dgrad_math, g->act_f16);
+  // ---- stem kernel (forward, C <= 4, stride-2 W windows): forced by tune code 4096, or by the heuristic when un-tuned
+  if (which == 0 && ((fbm & 4096) || (fbm == 0 && stem_heuristic_on()))) {
+    StemParams sp;
+    if (stem_geometry(g, p, math, sp))
+      return IgemmCfg{64, 128, 1, sp.nsteps, 0, 0, math, 2, sp.bd, sp.bh, sp.bw, math == 3};
+  }
+  if (fbm & 4096) { fbm = 0; fs = 0; tail = 0; }           // not runnable as asked
   // ---- LDS-halo kernel: forced by the tune code, or by the heuristic for multi-tap classes with enough channels and tiles
   {
     int bd = box & 255, bh = (box >> 8) & 255, bw = (box >> 16) & 255, rows = fbm & 1023;
     bool use = false;
     HaloParams hp;
-    if (fbm & 2048) {
+    if ((fbm & 2048) && !(fbm & 4096)) {
       use = bd > 0 && halo_geometry(c, p, bd, bh, bw, math, hp);
     } else if (fbm == 0 && halo_heuristic_on() && (c.ntaps >= 3 || math == 3) && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
       double cost = 0, cost2 = 0;
@@ -1134,6 +1193,20 @@ int run_class_halo(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& c
   return gca_launch_status();
 }
 
+// The forward class on the stem kernel.
+int run_class_stem(const gca_conv_geom* g, const IgemmCfg& cf, const float* src, const float* apack, const float* bias, float* dst,
+                   float* psum, float* psq, const IgemmParams& p, hipStream_t st) {
+  StemParams sp;
+  if (!stem_geometry(g, p, cf.math, sp) || sp.bd != cf.bd || sp.bh != cf.bh || sp.bw != cf.bw) return GCA_EINVAL;
+  sp.g.splits = 1; sp.g.kt_per_split = sp.nsteps;
+  sp.g.tilesM = cdiv(p.DK, 64);
+  const long long tn = (long long)g->N * sp.nbd * sp.nbh * sp.nbw;
+  if (tn > 0x7fffffffLL) return GCA_EINVAL;
+  sp.g.tilesN = (int)tn; sp.g.tileN_off = 0;
+  sp.g.P = (int)tn;
+  return stem_launch(cf.math, sp, src, reinterpret_cast<const unsigned char*>(apack), bias, dst, psum, psq, st);
+}
+
 int64_t ws_bytes_for(const gca_conv_geom* g, int which) {
   std::vector<ClassInfo> cls;
   build_classes(g, which, cls);
@@ -1167,7 +1240,7 @@ int conv_math() {
 
 extern "C" {
 
-int gca_version(void) { return 9; }
+int gca_version(void) { return 10; }
 
 int gca_set_conv_math(int mode) {
   if (mode < 0 || mode > 2) return GCA_EINVAL;
@@ -1191,10 +1264,10 @@ static void pack_params_of(const gca_conv_geom* g, int which, const ClassInfo& c
     IgemmParams ip{};
     class_params(g, which, c, ip);
     const IgemmCfg cf = cfg_for(g, which, c, ip, nclasses);
-    p.fmt = cf.halo; p.math = cf.math; p.SC = c.srcC; p.nsteps = cdiv(c.srcC, 16) * c.ntaps;
+    p.fmt = cf.halo; p.math = cf.math; p.SC = c.srcC; p.nsteps = cf.halo == 2 ? cf.kt_per_split : cdiv(c.srcC, 16) * c.ntaps;
   }
   p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = (int)c.Kpad; p.Mrows = pack_rows(c.M);
-  p.ntaps = c.ntaps; p.nb = c.nb; p.nc = c.nc;
+  p.ntaps = p.fmt == 2 ? g->kd * g->kh : c.ntaps; p.nb = c.nb; p.nc = c.nc;       // (stem pack: reduction rows per channel)
   p.k0d = c.k0[0]; p.k0h = c.k0[1]; p.k0w = c.k0[2]; p.sd = c.ks[0]; p.sh = c.ks[1]; p.sw = c.ks[2];
   p.KH = g->kh; p.KW = g->kw; p.T = T;
   if (which == 0) { p.s_ch = T; p.s_m = (long long)g->C * T; }       // W[m=ko][ch=c][tap]
@@ -1328,12 +1401,13 @@ int64_t gca_conv_pack_layout(const gca_conv_geom* g, int which) {
   build_classes(g, which, cls);
   int64_t sig = 0;
   for (const ClassInfo& c : cls) {
-    int code = 0;                                  // 0: k-major fp32 rows; 4 + arithmetic: LDS-halo layout
+    int code = 0;                                  // 0: k-major fp32 rows; 4 + arithmetic: LDS-halo layout; 1..3: stem layout
     if (c.ntaps) {
       IgemmParams p{};
       class_params(g, which, c, p);
       const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-      if (cf.halo) code = 4 + cf.math;
+      if (cf.halo == 2) code = cf.math;             // stem layout (arithmetic 1..3)
+      else if (cf.halo) code = 4 + cf.math;
     }
     sig = sig * 8 + code;
     if (sig > (1LL << 56)) sig %= 1000000007LL;    // (more than 18 classes: a hash is enough)
@@ -1350,7 +1424,7 @@ int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
     IgemmParams p{};
     class_params(g, which, c, p);
     const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | (cf.halo << 14) | (cf.h << 15);
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | ((cf.halo == 1) << 14) | (cf.h << 15) | ((cf.halo == 2) << 16);
     return GCA_OK;
   }
   return GCA_EINVAL;
@@ -1383,6 +1457,7 @@ int gca_conv_fwd(const gca_conv_geom* g, const void* x_, const float* wpack, con
   class_params(g, 0, c, p);
   p.accumulate = 0;
   const IgemmCfg cf = cfg_for(g, 0, c, p, 1);
+  if (cf.halo == 2) return run_class_stem(g, cf, x, wpack, bias, y, stat_sum, stat_sq, p, (hipStream_t)stream);
   if (cf.halo)
     return run_class_halo(g, c, cf, x, wpack, reinterpret_cast<const int2*>(table), bias, y, stat_sum, stat_sq,
                           reinterpret_cast<float*>(ws), p, (hipStream_t)stream);

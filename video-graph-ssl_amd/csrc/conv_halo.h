@@ -27,7 +27,26 @@ struct HaloCfg {
   int math;
 };
 
-// One thread per (step, row, pair of channels) of the halo pack (PackParams fmt 1).
+// Kernel parameter block of conv_stem_kernel (conv3d_stem.hip): forward class of a conv with <= 4 input channels, stride 2
+// and <= 8 taps along W.
+struct StemParams {
+  IgemmParams g;
+  int bd, bh, bw, lbh, lbw;     // box of 128 output positions per tile, w fastest; powers of two
+  int nbd, nbh, nbw;            // boxes per clip
+  int hd, hh;                   // halo rows: (bd-1)*sd + kd, (bh-1)*sh + kh
+  int wp;                       // elements of one phase-row copy: bw + 4 (even)
+  int sd, sh, pd, ph, pw;       // strides in d, h (2 in w), padding
+  int kd, kh, kw;
+  int nrows, nsteps;            // C*kd*kh reduction rows, two per step
+  int Mrows;                    // rows of one packed A step
+  int rowoff_bytes;             // LDS bytes of the row-offset table (multiple of 16)
+  unsigned cs_bytes;            // channel stride of x (bytes)
+  unsigned pack_bytes;
+  gca_magic m_w2, m_hdh, m_hh;  // divisions of the staging loop: 2*wp, hd*hh, hh
+};
+
+// One thread per (step, row, pair of k) of the halo pack (PackParams fmt 1) or of the stem pack (fmt 2: k = 8*half + e, half
+// -> reduction row (c, kd-tap, kh-tap) = 2*step + half, e -> kw-tap 0,2,4,6 | 1,3,5,7; taps >= KW and rows past the end are 0).
 __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, unsigned char* __restrict__ packed,
                                                    const PackParams& p, long long first, long long step, long long end) {
   const int rowbytes = p.math == 3 ? 32 : (p.math == 2 ? 96 : 64);
@@ -41,7 +60,16 @@ __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, 
     const int tap = ((p.k0d + p.sd * a) * p.KH + (p.k0h + p.sh * b)) * p.KW + (p.k0w + p.sw * c);
     float v0 = 0.f, v1 = 0.f;
     const int ch = chunk * 16 + 2 * kp;
-    if (m < p.M) {
+    if (p.fmt == 2) {
+      const int rho = 2 * s + (kp >> 2), e0 = 2 * (kp & 3);                      // reduction row, first of the two k of this item
+      if (m < p.M && rho < p.SC * p.ntaps) {                                     // (ntaps = kd*kh rows per channel for fmt 2)
+        const int c = rho / p.ntaps, ab = rho - c * p.ntaps;
+        const int t0 = e0 < 4 ? 2 * e0 : 2 * (e0 - 4) + 1, t1 = e0 + 1 < 4 ? 2 * (e0 + 1) : 2 * (e0 + 1 - 4) + 1;
+        const float* wr = w + (long long)c * p.s_ch + (long long)ab * p.KW + (long long)m * p.s_m;
+        if (t0 < p.KW) v0 = wr[t0];
+        if (t1 < p.KW) v1 = wr[t1];
+      }
+    } else if (m < p.M) {
       if (ch < p.SC) v0 = w[(long long)ch * p.s_ch + tap + (long long)m * p.s_m];
       if (ch + 1 < p.SC) v1 = w[(long long)(ch + 1) * p.s_ch + tap + (long long)m * p.s_m];
     }
@@ -65,6 +93,10 @@ __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, 
     }
   }
 }
+
+size_t stem_lds_bytes(const StemParams& sp, int math);
+int stem_launch(int math, const StemParams& sp, const void* src, const unsigned char* apack, const float* bias, void* dst,
+                float* psum, float* psq, hipStream_t st);
 
 inline int halo_row_bytes(int math) { return math == 3 ? 32 : (math == 2 ? 96 : 64); }
 size_t halo_lds_bytes(int bm, int math, int P);

@@ -56,7 +56,10 @@ inline long long pack_reserve(const ClassInfo& c) {
   const long long rows = pack_rows(c.M);
   const long long flat = c.Kpad * rows;
   const long long halo = c.srcC >= 8 && c.ntaps <= 64 ? (long long)cdiv(c.srcC, 16) * c.ntaps * rows * 24 : 0;   // halo_geometry()'s limits
-  return halo > flat ? halo : flat;
+  // stem kernels (conv3d_stem.hip): 16 k per pair of (channel, kd, kh) rows, up to 96 bytes (24 floats) per packed row
+  const long long stem = c.srcC <= 4 && c.nc <= 8 && c.m[2] == 2 ? (long long)cdiv(c.srcC * c.na * c.nb, 2) * rows * 24 : 0;
+  const long long m = halo > stem ? halo : stem;
+  return m > flat ? m : flat;
 }
 
 inline void build_classes(const gca_conv_geom* g, int which, std::vector<ClassInfo>& out) {
@@ -162,12 +165,12 @@ struct PackParams {
   int ntaps, nb, nc;           // class tap grid: ntaps = na*nb*nc
   int k0d, k0h, k0w, sd, sh, sw;
   int KH, KW, T;               // full kernel
-  int fmt, SC, nsteps, math;   // fmt 1: reduction channels, chunks*ntaps, arithmetic mode of the consumer
+  int fmt, SC, nsteps, math;   // fmt 1 (LDS-halo) / 2 (stem): reduction channels, steps, arithmetic mode of the consumer
   long long s_ch, s_m;         // element strides of `ch` and `m` in W
 };
 // work items of a pack job: fmt 0 one per packed float, fmt 1 one per (step, row, channel pair)
 __host__ __device__ inline long long pack_items(const PackParams& p) {
-  return p.fmt == 1 ? (long long)p.nsteps * p.Mrows * 8 : (long long)p.Mrows * p.Kpad;
+  return p.fmt >= 1 ? (long long)p.nsteps * p.Mrows * 8 : (long long)p.Mrows * p.Kpad;
 }
 
 }  // namespace gca_conv

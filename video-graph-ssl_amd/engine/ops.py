@@ -314,6 +314,8 @@ class ConvPlan:
         if which == 0:
             cands = [c + (0,) for c in self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)]
             cands += self._halo_candidates(0, K)
+            if g.C <= 4 and g.sw == 2 and g.kw <= 8:
+                cands.append((4096 | 64, 1, 0))                   # stem kernel (conv3d_stem.hip), box by its own heuristic
         elif which == 1:
             cands = [c + (0,) for c in self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)]
             cands += self._halo_candidates(1, g.C)
@@ -330,8 +332,9 @@ class ConvPlan:
             if which == 2 and self.cfg(2)[3] & 255 != c[0]:      # shape not available for this tap count
                 return None
             if which < 2:
-                if bool(c[0] & 2048) != bool((self.cfg(which)[3] >> 14) & 1):       # halo asked for but not runnable here
-                    return None
+                kc = self.cfg(which)[3]
+                if bool(c[0] & 2048) != bool((kc >> 14) & 1) or bool(c[0] & 4096) != bool((kc >> 16) & 1):
+                    return None                                   # halo / stem kernel asked for but not runnable here (or vice versa)
                 if layout() != packed_as[0]:
                     if repack is None:
                         return None
