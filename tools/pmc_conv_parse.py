@@ -5,7 +5,7 @@ cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(root + '/p*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        if 'conv_igemm' not in n and 'conv_wgrad' not in n and 'conv_halo' not in n:
+        if 'conv_igemm' not in n and 'conv_wgrad' not in n and 'conv_halo' not in n and 'conv_stem' not in n:
             continue
         s = re.sub(r'\(anonymous namespace\)::', '', n); s = re.sub(r'^void ', '', s).split('(')[0]
         key = '%s grid=%s' % (s, r['Grid_Size'])

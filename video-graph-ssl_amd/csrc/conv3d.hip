@@ -883,6 +883,12 @@ inline bool halo_heuristic_on() {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// LDS layout of a stem halo row (conv3d_stem.hip): [phase][part][copy][cd dwords].  (Measured and not kept: cd = 16 (mod 32)
+// with a row pitch of bw/2 (mod 32) dwords per output row, which makes every 32-lane read group conflict-free on paper --
+// the 2.7x larger rows cost more in occupancy and box shape than the conflicts do: 0.64 vs 0.66 ms on the R(2+1)D-18 stem
+// in bf16x6, 2.6 vs 1.6 ms on the 3D-ResNet stem in fp16.)
+inline int stem_copy_dwords(int bw) { return (bw + 4) / 2; }
+inline int stem_row_bytes(int bw, int sh, int np) { (void)sh; return 4 * np * stem_copy_dwords(bw) * 4; }
 // ---- stem kernels (conv3d_stem.hip): forward class, <= 4 input channels, stride 2 and <= 8 taps along W ---------------------
 // GCA_STEM=0 keeps un-tuned stems on the gather kernels (A/B runs; the forced tune code 4096 is still honoured)
 inline bool stem_heuristic_on() {
@@ -890,47 +896,49 @@ inline bool stem_heuristic_on() {
   if (on < 0) { const char* e = getenv("GCA_STEM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on != 0;
 }
-// Fills sp (box = the 128-position tiling with the least staging work per output that fits two workgroups per CU, or one if
+// Fills sp (tile = 64 channels x 256 positions, or 128 x 128 for more than 64 output channels; box = the tiling with the least staging work per output that fits two workgroups per CU, or one if
 // none does); false when the conv cannot run there.
 inline bool stem_geometry(const gca_conv_geom* g, const IgemmParams& p, int math, StemParams& sp) {
   if (math < 1 || math > 3 || g->C > 4 || g->sw != 2 || g->kw > 8 || g->x_batch_stride % 4 != 0) return false;
-  if ((long long)g->N * g->OD * g->OH * g->OW < 128 * 64) return false;          // not worth a halo
+  if ((long long)g->N * g->OD * g->OH * g->OW < 256 * 32) return false;          // not worth a halo
   const int np = math == 3 ? 1 : (math == 2 ? 3 : 2);
-  const int pitch = (math == 3 ? 32 : (math == 2 ? 96 : 64)) + 16;
   const int nrows = g->C * g->kd * g->kh, nsteps = cdiv(nrows, 2);
-  const int rowoff_bytes = (int)gca_round_up(2 * nsteps * 4, 16);
+  // LDS tables: row offsets of the reduction rows (2 per step) + input-row origins of the halo (<= C*hd*hh, sized per box below)
   double best = 1e300;
   int bb[3] = {0, 0, 0};
+  const int wmr = g->K > 64 ? 4 : 2, npos = 512 / wmr;         // wave rows; positions per tile (4 waves of 32 rows x 128 columns)
   for (int pass = 0; pass < 2 && bb[0] == 0; ++pass) {
     const size_t cap = pass == 0 ? (size_t)(76 << 10) : (size_t)(156 << 10);
-    for (int bd = 1; bd <= 128; bd *= 2)
-      for (int bh = 1; bd * bh <= 128; bh *= 2) {
-        const int bw = 128 / (bd * bh);
+    for (int bd = 1; bd <= npos; bd *= 2)
+      for (int bh = 1; bd * bh <= npos; bh *= 2) {
+        const int bw = npos / (bd * bh);
         if (bw < 4 || bw > 64) continue;
         if (bd > 2 * g->OD || bh > 2 * g->OH || bw > 2 * g->OW) continue;
         const int hd = (bd - 1) * g->sd + g->kd, hh = (bh - 1) * g->sh + g->kh, wp = bw + 4;
-        const size_t lds = (size_t)rowoff_bytes + 2 * 64 * pitch + (size_t)g->C * hd * hh * 4 * np * wp * 2;
+        const size_t lds = gca_round_up((2 * nsteps + g->C * hd * hh) * 4, 16) + (size_t)g->C * hd * hh * stem_row_bytes(bw, g->sh, np);
         if (lds > cap) continue;
         const double cover = (double)cdiv(g->OD, bd) * bd / g->OD * cdiv(g->OH, bh) * bh / g->OH * cdiv(g->OW, bw) * bw / g->OW;
-        const double staging = (double)g->C * hd * hh * 2 * wp / 128.0;           // staged elements per output position
+        const double staging = (double)g->C * hd * hh * 2 * wp / (double)npos;    // staged elements per output position
         const double cost = cover * (1.0 + staging / (double)(nsteps * 8)) * (bw >= 8 ? 1.0 : 1.15);
         if (cost < best) { best = cost; bb[0] = bd; bb[1] = bh; bb[2] = bw; }
       }
   }
   if (bb[0] == 0) return false;
   sp.g = p;
+  sp.wm = wmr;
   sp.bd = bb[0]; sp.bh = bb[1]; sp.bw = bb[2]; sp.lbh = ilog2(bb[1]); sp.lbw = ilog2(bb[2]);
   sp.nbd = cdiv(g->OD, sp.bd); sp.nbh = cdiv(g->OH, sp.bh); sp.nbw = cdiv(g->OW, sp.bw);
   sp.hd = (sp.bd - 1) * g->sd + g->kd; sp.hh = (sp.bh - 1) * g->sh + g->kh; sp.wp = sp.bw + 4;
+  sp.cd = stem_copy_dwords(sp.bw); sp.hrowb = stem_row_bytes(sp.bw, g->sh, np);
   sp.sd = g->sd; sp.sh = g->sh; sp.pd = g->pd; sp.ph = g->ph; sp.pw = g->pw;
   sp.kd = g->kd; sp.kh = g->kh; sp.kw = g->kw;
   sp.nrows = nrows; sp.nsteps = nsteps;
   sp.Mrows = pack_rows(g->K);
-  sp.rowoff_bytes = rowoff_bytes;
+  sp.rowoff_bytes = (int)gca_round_up((2 * nsteps + g->C * sp.hd * sp.hh) * 4, 16);
   sp.cs_bytes = (unsigned)((long long)g->D * g->H * g->W * (g->act_f16 ? 2 : 4));
   const long long pb = (long long)nsteps * sp.Mrows * (math == 3 ? 32 : (math == 2 ? 96 : 64));
   sp.pack_bytes = pb > 0xfffff000LL ? 0xfffff000u : (unsigned)pb;
-  sp.m_w2 = gca_make_magic((unsigned)(2 * sp.wp)); sp.m_hdh = gca_make_magic((unsigned)(sp.hd * sp.hh));
+  sp.m_w2 = gca_make_magic((unsigned)sp.wp); sp.m_hdh = gca_make_magic((unsigned)(sp.hd * sp.hh));
   sp.m_hh = gca_make_magic((unsigned)sp.hh);
   return true;
 }
@@ -998,7 +1006,7 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
   if (which == 0 && ((fbm & 4096) || (fbm == 0 && stem_heuristic_on()))) {
     StemParams sp;
     if (stem_geometry(g, p, math, sp))
-      return IgemmCfg{64, 128, 1, sp.nsteps, 0, 0, math, 2, sp.bd, sp.bh, sp.bw, math == 3};
+      return IgemmCfg{32 * sp.wm, 512 / sp.wm, 1, sp.nsteps, 0, 0, math, 2, sp.bd, sp.bh, sp.bw, math == 3};
   }
   if (fbm & 4096) { fbm = 0; fs = 0; tail = 0; }           // not runnable as asked
   // ---- LDS-halo kernel: forced by the tune code, or by the heuristic for multi-tap classes with enough channels and tiles
@@ -1199,7 +1207,7 @@ int run_class_stem(const gca_conv_geom* g, const IgemmCfg& cf, const float* src,
   StemParams sp;
   if (!stem_geometry(g, p, cf.math, sp) || sp.bd != cf.bd || sp.bh != cf.bh || sp.bw != cf.bw) return GCA_EINVAL;
   sp.g.splits = 1; sp.g.kt_per_split = sp.nsteps;
-  sp.g.tilesM = cdiv(p.DK, 64);
+  sp.g.tilesM = cdiv(p.DK, 32 * sp.wm);
   const long long tn = (long long)g->N * sp.nbd * sp.nbh * sp.nbw;
   if (tn > 0x7fffffffLL) return GCA_EINVAL;
   sp.g.tilesN = (int)tn; sp.g.tileN_off = 0;

@@ -12,12 +12,12 @@
 // W phase (and into bf16 parts), each phase row twice -- as is and shifted by one element -- so that every lane's 4-element
 // run starts on a 4-byte boundary whatever the parity of its column:
 //
-//     Hs[(c, zd, zh)][phase][copy][part][wp]   16-bit elements
+//     Hs[(c, zd, zh)][phase][part][copy][wp (padded)]   16-bit elements
 //
 // and the B fragment of a k-step is two ds_read2_b32 per part (E run | O run) at  row(c,a,b) + lane position  -- no
 // per-element gathers, no operand split in the loop.  k = 7 (the pad of the odd run) multiplies a zero weight.  Weights are
 // packed [step][row][part][16] in the same k order, pre-split (conv_halo.h, fmt 2); two (c,a,b) rows per step (the lane
-// halves).  A tile is a box of 128 output positions x 64 output channels; epilogue as in conv3d_halo.hip.
+// halves).  A tile is a box of 256 output positions x 64 output channels; epilogue as in conv3d_halo.hip.
 #include <cstring>
 #include "conv_igemm_host.h"
 #include "conv_halo.h"
@@ -27,27 +27,27 @@ using namespace gca_conv;
 namespace {
 
 constexpr int rowb(int math) { return math == 3 ? 32 : (math == 2 ? 96 : 64); }     // bytes of one packed 16-k row
-constexpr int pitchb(int math) { return rowb(math) + 16; }
 constexpr int nparts(int math) { return math == 3 ? 1 : (math == 2 ? 3 : 2); }
 __device__ __forceinline__ unsigned short f16_bits(float v) { return __builtin_bit_cast(unsigned short, (_Float16)v); }
 
-template <int MATH>
+template <int MATH, int WM>
 __global__ __launch_bounds__(256, 2) void conv_stem_kernel(
     const void* __restrict__ src, const unsigned char* __restrict__ apack, const float* __restrict__ bias,
     void* __restrict__ dst, float* __restrict__ psum, float* __restrict__ psq, const StemParams sp) {
   static_assert(MATH >= 1 && MATH <= 3, "bf16x3 / bf16x6 / fp16 storage");
   constexpr bool F16 = MATH == 3;
   constexpr unsigned ES = F16 ? 2u : 4u;
-  constexpr int TM = 2, BM = 64;
-  constexpr int ROWB = rowb(MATH), PITCH = pitchb(MATH), NP = nparts(MATH);
-  constexpr int RPC = ROWB / 16, NPC = BM * RPC, A_PC = (NPC + 255) / 256;
+  // waves WM (rows) x WN (columns), 32 rows x 128 columns each: 64 x 256 (output channels <= 64) or 128 x 128 per workgroup
+  static_assert(WM == 2 || WM == 4, "wave grid");
+  constexpr int WN = 4 / WM, BM = 32 * WM, TN = 4;
+  constexpr int ROWB = rowb(MATH), NP = nparts(MATH);
   const IgemmParams& p = sp.g;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* const rowoff = reinterpret_cast<int*>(smem);                       // [2 * nsteps] LDS byte offset of halo row (c, a, b)
-  unsigned char* const As = smem + sp.rowoff_bytes;                       // [2][BM][PITCH]
-  unsigned char* const Hs = As + 2 * BM * PITCH;                          // halo rows
+  unsigned* const rowbase = reinterpret_cast<unsigned*>(smem) + 2 * sp.nsteps;   // [C*hd*hh] byte offset of the input row in x (or ~0)
+  unsigned char* const Hs = smem + sp.rowoff_bytes;                       // halo rows (>= 2 KB: also the statistics scratch of the epilogue)
 
-  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6, lh = lane >> 5, ll = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WN, wn = wave % WN, lh = lane >> 5, ll = lane & 31;
   int bid = gca_xcd_remap(blockIdx.x, gridDim.x);
   const int tileM = bid % p.tilesM, tileN = bid / p.tilesM;
   const int per_img = sp.nbd * sp.nbh * sp.nbw;
@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(
   const int q0d = tbd * sp.bd, q0h = tbh * sp.bh, q0w = tbw * sp.bw;
 
   const int wp = sp.wp;                                  // elements of one phase row copy (even)
-  const unsigned PARTB = (unsigned)wp * 2u;              // bytes: one part of one copy
-  const unsigned COPYB = PARTB * NP, PHASEB = 2u * COPYB, HROWB = 2u * PHASEB;
+  // halo row = [phase][part][copy][cd dwords]; copy stride and row pitch come from the host (stem_copy_dwords / stem_row_bytes)
+  const unsigned COPYB = (unsigned)sp.cd * 4u, PARTB = 2u * COPYB, PHASEB = PARTB * NP, HROWB = (unsigned)sp.hrowb;
   const int khd = sp.kd * sp.kh;
+  // (m_w2 divides by wp here: the dword tasks of one halo row)
   for (int r = tid; r < 2 * sp.nsteps; r += 256) {
     int off = 0;
     if (r < sp.nrows) {
@@ -70,114 +71,110 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(
     rowoff[r] = off;                                     // rows past the end multiply zero weights: any finite data will do
   }
 
-  // ---- A pieces of this thread (as conv3d_halo.hip)
+  // ---- A fragments come STRAIGHT from the packed weights (L1/L2-resident): a wave owns ONE 32-row tile (the two wave rows
+  // split M, so the weights cross the L1 once per wave pair instead of once per wave) and reads its 16 bytes per part at
+  // step*astep + (tileM*BM + 32 wm + ll)*ROWB + 32 part + 16 lh.  One step ahead in registers; no LDS copy, no barrier in the k loop.
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(apack), 0, sp.pack_bytes, 0x00020000);
-  unsigned avoff[A_PC], awoff[A_PC];
-#pragma unroll
-  for (int u = 0; u < A_PC; ++u) {
-    const int i = tid + 256 * u;
-    const int row = i / RPC, sub = i - row * RPC;
-    avoff[u] = i < NPC ? (unsigned)(tileM * BM) * ROWB + (unsigned)i * 16u : 0xffffffffu;
-    awoff[u] = (unsigned)(i < NPC ? row : 0) * PITCH + (unsigned)sub * 16u;
-  }
+  const unsigned avoff = (unsigned)(tileM * BM + 32 * wm + ll) * ROWB + (unsigned)lh * 16u;
   const unsigned astep = (unsigned)sp.Mrows * ROWB;
-  uint4 areg[A_PC];
+  float4 afn[NP];
   auto a_issue = [&](int s) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < A_PC; ++u)
-      areg[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)avoff[u], (int)((unsigned)s * astep), 0));
-  };
-  auto a_store = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < A_PC; ++u)
-      if (u + 1 < A_PC || NPC % 256 == 0 || tid + 256 * u < NPC)
-        *reinterpret_cast<uint4*>(As + buf * (BM * PITCH) + awoff[u]) = areg[u];
+    for (int q = 0; q < NP; ++q) {
+      const f32x4 f = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, (int)(avoff + 32u * q), (int)((unsigned)s * astep), 0));
+      afn[q] = make_float4(f.x, f.y, f.z, f.w);
+    }
   };
   a_issue(0);
 
-  // ---- stage the halo: task = (halo row hr = (c, zd, zh), u = column offset from the tile's first input column); element
-  // x[c][s0d + zd][s0h + zh][s0w + u] goes to phase u & 1, index u >> 1 of copy 0 and index (u >> 1) - 1 of copy 1
+  // ---- stage the halo.  A task is one DWORD (two consecutive elements) of a phase row in both copies: it loads S[2j], S[2j+1],
+  // S[2j+2] of its phase (input columns s0w + 2(2j + e) + phase), and writes the pair (S[2j], S[2j+1]) to copy 0 and the pair
+  // (S[2j+1], S[2j+2]) to copy 1 -- the bf16 split works on pairs anyway, the LDS stores are conflict-free b32s, and the only
+  // division per task is the one by the row length (row origins come from a table built once per tile).
   {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(src), 0, p.src_bytes, 0x00020000);
-    const int W2 = 2 * wp;
     const int nhrows = p.SC * sp.hd * sp.hh;
-    const int ntasks = nhrows * W2;
     const int s0d = q0d * sp.sd - sp.pd, s0h = q0h * sp.sh - sp.ph, s0w = q0w * 2 - sp.pw;
     const unsigned ibase = (unsigned)((long long)img * p.src_nstride);
     const int hdh = sp.hd * sp.hh;
-    constexpr int UF = 8;
+    for (int hr = tid; hr < nhrows; hr += 256) {
+      const int c = (int)gca_fdiv((unsigned)hr, sp.m_hdh), rem = hr - c * hdh;
+      const int zd = (int)gca_fdiv((unsigned)rem, sp.m_hh), zh = rem - zd * sp.hh;
+      const int id = s0d + zd, ih = s0h + zh;
+      const bool ok = (unsigned)id < (unsigned)p.SD && (unsigned)ih < (unsigned)p.SH;
+      rowbase[hr] = ok ? (ibase + (unsigned)((id * p.SH + ih) * p.SW)) * ES + (unsigned)c * sp.cs_bytes : 0xffffffffu;
+    }
+    __syncthreads();
+    const int hw = wp >> 1;                               // dwords per phase-row copy
+    const int ntasks = nhrows * wp;
+    constexpr int UF = 4;
     for (int t0 = tid; t0 < ntasks; t0 += 256 * UF) {
-      float v[UF];
-      int hrw[UF], uu[UF];
+      float v[UF][3];
+      unsigned wo[UF];
 #pragma unroll
       for (int k = 0; k < UF; ++k) {
         const int task = t0 + 256 * k;
-        const int hr = (int)gca_fdiv((unsigned)task, sp.m_w2), u = task - hr * W2;
-        const int c = (int)gca_fdiv((unsigned)hr, sp.m_hdh), rem = hr - c * hdh;
-        const int zd = (int)gca_fdiv((unsigned)rem, sp.m_hh), zh = rem - zd * sp.hh;
-        const int id = s0d + zd, ih = s0h + zh, iw = s0w + u;
-        const bool ok = task < ntasks && (unsigned)id < (unsigned)p.SD && (unsigned)ih < (unsigned)p.SH && (unsigned)iw < (unsigned)p.SW;
-        const unsigned e = ibase + (unsigned)((id * p.SH + ih) * p.SW + iw);
-        const unsigned vo = ok ? e * ES + (unsigned)c * sp.cs_bytes : 0xffffffffu;      // (the channel differs per lane: not an soffset)
-        if (F16) v[k] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)vo, 0, 0));
-        else v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, 0, 0));
-        hrw[k] = task < ntasks ? hr : -1;
-        uu[k] = u;
+        const int hr = (int)gca_fdiv((unsigned)task, sp.m_w2), slot = task - hr * wp;
+        const int ph = slot >= hw ? 1 : 0, j = slot - ph * hw;
+        const unsigned rb = task < ntasks ? rowbase[hr] : 0xffffffffu;
+        const int iw0 = s0w + 4 * j + ph;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+          const int iw = iw0 + 2 * e;
+          const unsigned vo = (rb == 0xffffffffu || (unsigned)iw >= (unsigned)p.SW) ? 0xffffffffu : rb + (unsigned)iw * ES;
+          if (F16) v[k][e] = __uint_as_float((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, (int)vo, 0, 0));
+          else v[k][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, 0, 0));
+        }
+        wo[k] = task < ntasks ? (unsigned)hr * HROWB + (unsigned)ph * PHASEB + (unsigned)j * 4u : 0xffffffffu;
       }
 #pragma unroll
       for (int k = 0; k < UF; ++k) {
-        if (hrw[k] < 0) continue;
-        unsigned short part[3];
-        if (F16) part[0] = (unsigned short)__float_as_uint(v[k]);
-        else if (MATH == 2) {
+        if (wo[k] == 0xffffffffu) continue;
+        unsigned char* d = Hs + wo[k];
+        if (F16) {
+          const unsigned a = __float_as_uint(v[k][0]), b = __float_as_uint(v[k][1]), c = __float_as_uint(v[k][2]);
+          *reinterpret_cast<unsigned*>(d) = a | (b << 16);
+          *reinterpret_cast<unsigned*>(d + COPYB) = b | (c << 16);
+        } else if (MATH == 2) {
           unsigned h, m, l;
-          split_bf16x3(v[k], 0.f, h, m, l);
-          part[0] = (unsigned short)h; part[1] = (unsigned short)m; part[2] = (unsigned short)l;
+          split_bf16x3(v[k][0], v[k][1], h, m, l);
+          *reinterpret_cast<unsigned*>(d) = h; *reinterpret_cast<unsigned*>(d + PARTB) = m; *reinterpret_cast<unsigned*>(d + 2 * PARTB) = l;
+          split_bf16x3(v[k][1], v[k][2], h, m, l);
+          *reinterpret_cast<unsigned*>(d + COPYB) = h; *reinterpret_cast<unsigned*>(d + COPYB + PARTB) = m;
+          *reinterpret_cast<unsigned*>(d + COPYB + 2 * PARTB) = l;
         } else {
           unsigned h, l;
-          split_bf16x2(v[k], 0.f, h, l);
-          part[0] = (unsigned short)h; part[1] = (unsigned short)l;
-        }
-        const int ph = uu[k] & 1, idx = uu[k] >> 1;
-        unsigned char* rowp = Hs + (unsigned)hrw[k] * HROWB + (unsigned)ph * PHASEB;
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-          *reinterpret_cast<unsigned short*>(rowp + q * PARTB + idx * 2) = part[q];
-          if (idx > 0) *reinterpret_cast<unsigned short*>(rowp + COPYB + q * PARTB + (idx - 1) * 2) = part[q];
+          split_bf16x2(v[k][0], v[k][1], h, l);
+          *reinterpret_cast<unsigned*>(d) = h; *reinterpret_cast<unsigned*>(d + PARTB) = l;
+          split_bf16x2(v[k][1], v[k][2], h, l);
+          *reinterpret_cast<unsigned*>(d + COPYB) = h; *reinterpret_cast<unsigned*>(d + COPYB + PARTB) = l;
         }
       }
     }
-    // the last element of copy 1 (index wp - 1) has no source: it is only ever multiplied by the zero pad weight, but must be finite
-    for (int r = tid; r < nhrows * 2 * NP; r += 256) {
-      const int hr = r / (2 * NP), rem = r - hr * (2 * NP), ph = rem / NP, q = rem - ph * NP;
-      *reinterpret_cast<unsigned short*>(Hs + (unsigned)hr * HROWB + (unsigned)ph * PHASEB + COPYB + q * PARTB + (wp - 1) * 2) = 0;
-    }
   }
 
-  // ---- per-lane column state
-  const int cidx = wn * 32 + ll;
-  const int zw = cidx & (sp.bw - 1), t1 = cidx >> sp.lbw;
-  const int zh = t1 & (sp.bh - 1), zd = t1 >> sp.lbh;
-  const int cq0 = q0d + zd, cq1 = q0h + zh, cq2 = q0w + zw;
-  const bool cval = cq0 < p.QD && cq1 < p.QH && cq2 < p.QW;
-  const unsigned bpos = (unsigned)((zd * sp.sd) * sp.hh + zh * sp.sh) * HROWB + (unsigned)(zw & 1) * COPYB + (unsigned)(zw & ~1) * 2u;
-  const unsigned aoff = (unsigned)ll * PITCH + (unsigned)lh * 16u;
-
-  f32x16 acc[TM];
+  // ---- per-lane column state: column tile j of this wave = columns wn*128 + 32 j + ll of the box
+  unsigned bpos[TN];
+  bool cval[TN];
+  int cq[TN][3];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int j = 0; j < TN; ++j) {
+    const int cidx = wn * 128 + j * 32 + ll;
+    const int zw = cidx & (sp.bw - 1), t1 = cidx >> sp.lbw;
+    const int zh = t1 & (sp.bh - 1), zd = t1 >> sp.lbh;
+    cq[j][0] = q0d + zd; cq[j][1] = q0h + zh; cq[j][2] = q0w + zw;
+    cval[j] = cq[j][0] < p.QD && cq[j][1] < p.QH && cq[j][2] < p.QW;
+    bpos[j] = (unsigned)((zd * sp.sd) * sp.hh + zh * sp.sh) * HROWB + (unsigned)(zw & 1) * COPYB + (unsigned)(zw & ~1) * 2u;
+  }
 
-  a_store(0);
-  __syncthreads();                                       // publishes rowoff, the halo and A tile 0
-  a_issue(min(1, sp.nsteps - 1));
-  int buf = 0;
-  unsigned ro = (unsigned)rowoff[lh];
-  for (int s = 0; s < sp.nsteps; ++s) {
-    const unsigned ro_next = (unsigned)rowoff[2 * min(s + 1, sp.nsteps - 1) + lh];
-    float4 bf[NP], af[TM][NP];
-    const unsigned char* bp = Hs + bpos + ro;
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto load_b = [&](float4 (&bf)[NP], int j, unsigned ro) __attribute__((always_inline)) {
+    const unsigned char* bp = Hs + bpos[j] + ro;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
       // 4-byte aligned runs: two dwords each (ds_read2_b32), never one 8-byte access
@@ -185,78 +182,87 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(
       const unsigned* o = reinterpret_cast<const unsigned*>(bp + PHASEB + q * PARTB);   // odd-phase run:  taps 1, 3, 5, pad
       bf[q] = make_float4(__uint_as_float(e[0]), __uint_as_float(e[1]), __uint_as_float(o[0]), __uint_as_float(o[1]));
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int q = 0; q < NP; ++q)
-        af[i][q] = *reinterpret_cast<const float4*>(As + buf * (BM * PITCH) + aoff + i * (32 * PITCH) + 32 * q);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if constexpr (MATH == 3) {
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[i][0]), __builtin_bit_cast(f16x8, bf[0]), acc[i], 0, 0, 0);
+  };
+  auto mma = [&](f32x16& c, const float4 (&af)[NP], const float4 (&bf)[NP]) __attribute__((always_inline)) {
+    if constexpr (MATH == 3) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af[0]), __builtin_bit_cast(f16x8, bf[0]), c, 0, 0, 0);
+    } else {
+      const bf16x8 xh = __builtin_bit_cast(bf16x8, af[0]), xl = __builtin_bit_cast(bf16x8, af[NP - 1]);
+      const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[0]), yl = __builtin_bit_cast(bf16x8, bf[NP - 1]);
+      if (MATH == 2) {
+        const bf16x8 xm = __builtin_bit_cast(bf16x8, af[1]), ym = __builtin_bit_cast(bf16x8, bf[1]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, c, 0, 0, 0);
       } else {
-        const bf16x8 xh = __builtin_bit_cast(bf16x8, af[i][0]), xl = __builtin_bit_cast(bf16x8, af[i][NP - 1]);
-        const bf16x8 yh = __builtin_bit_cast(bf16x8, bf[0]), yl = __builtin_bit_cast(bf16x8, bf[NP - 1]);
-        if (MATH == 2) {
-          const bf16x8 xm = __builtin_bit_cast(bf16x8, af[i][1]), ym = __builtin_bit_cast(bf16x8, bf[1]);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, ym, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xm, yh, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, ym, acc[i], 0, 0, 0);
-        } else {
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, acc[i], 0, 0, 0);
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, acc[i], 0, 0, 0);
-        }
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, acc[i], 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, yh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yl, c, 0, 0, 0);
       }
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, yh, c, 0, 0, 0);
     }
-    a_store(buf ^ 1);                                    // tile s+1 -> the other buffer; fetch s+2 (clamped: exact vmcnt waits)
-    a_issue(min(s + 2, sp.nsteps - 1));
-    __syncthreads();
-    buf ^= 1;
+  };
+
+  __syncthreads();                                       // publishes rowoff and the halo (read-only from here on)
+  unsigned ro = (unsigned)rowoff[lh];
+  float4 bfc[NP], bfn[NP];
+  load_b(bfc, 0, ro);
+  for (int s = 0; s < sp.nsteps; ++s) {
+    const unsigned ro_next = (unsigned)rowoff[2 * min(s + 1, sp.nsteps - 1) + lh];
+    float4 af[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) af[q] = afn[q];
+    a_issue(min(s + 1, sp.nsteps - 1));                  // next step's weights (clamped: unconditional loads, exact waits)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {                       // the next column tile's fragments (or the next step's first) behind these MFMAs
+      if (j + 1 < TN) load_b(bfn, j + 1, ro); else load_b(bfn, 0, ro_next);
+      mma(acc[j], af, bfc);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) bfc[q] = bfn[q];
+    }
     ro = ro_next;
   }
+  __syncthreads();                                       // (the epilogue's statistics scratch overlays the halo)
 
   // ---- epilogue (C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)); see conv3d.hip
-  const int mbase = tileM * BM;
+  const int mbase = tileM * BM + 32 * wm;                  // first row of this wave
   const int rows_left = p.DK - mbase - 4 * lh;
   const int DHW = p.DH * p.DW;
   const unsigned DSP = (unsigned)(p.DD * DHW);
   const unsigned rowb_ = DSP * ES;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, p.dst_bytes, 0x00020000);
-  {
-    const unsigned dsp = (unsigned)(cq0 * DHW + cq1 * p.DW + cq2);
-    const unsigned vb = cval ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * ES : 0xffffffffu;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const unsigned dsp = (unsigned)(cq[j][0] * DHW + cq[j][1] * p.DW + cq[j][2]);
+    const unsigned vb = cval[j] ? (((unsigned)img * (unsigned)p.DK + (unsigned)(mbase + 4 * lh)) * DSP + dsp) * ES : 0xffffffffu;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rr = i * 32 + (r & 3) + 8 * (r >> 2);
-        const unsigned vo = rr < rows_left ? vb : 0xffffffffu;
-        float v = acc[i][r];
-        if (bias) v += bias[min(mbase + rr + 4 * lh, p.DK - 1)];
-        if (F16) __builtin_amdgcn_raw_buffer_store_b16(f16_bits(v), rd, (int)vo, (int)((unsigned)rr * rowb_), 0);
-        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)rr * rowb_), 0);
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int rr = (r & 3) + 8 * (r >> 2);
+      const unsigned vo = rr < rows_left ? vb : 0xffffffffu;
+      float v = acc[j][r];
+      if (bias) v += bias[min(mbase + rr + 4 * lh, p.DK - 1)];
+      if (F16) __builtin_amdgcn_raw_buffer_store_b16(f16_bits(v), rd, (int)vo, (int)((unsigned)rr * rowb_), 0);
+      else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rd, (int)vo, (int)((unsigned)rr * rowb_), 0);
+    }
   }
   if (psum) {
-    float* red = reinterpret_cast<float*>(As);                   // [4][BM][2] floats; the operand tiles are dead by now
+    float* red = reinterpret_cast<float*>(Hs);                   // [WN][BM][2] floats; the halo is dead by now
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int r = 0; r < 16; ++r) {
+      float sm = 0.f, sq = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = cval ? acc[i][r] : 0.f;
-        const float sm = half_wave_sum_hi(v), sq = half_wave_sum_hi(v * v);
-        const int rr = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (ll == 31) { red[(wn * BM + rr) * 2] = sm; red[(wn * BM + rr) * 2 + 1] = sq; }
-      }
+      for (int j = 0; j < TN; ++j) { const float v = cval[j] ? acc[j][r] : 0.f; sm += v; sq += v * v; }
+      sm = half_wave_sum_hi(sm);
+      sq = half_wave_sum_hi(sq);
+      const int rr = 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ll == 31) { red[(wn * BM + rr) * 2] = sm; red[(wn * BM + rr) * 2 + 1] = sq; }
     }
     __syncthreads();
-    if (tid < BM && mbase + tid < p.DK) {
-      const float sm = red[tid * 2] + red[(BM + tid) * 2] + red[(2 * BM + tid) * 2] + red[(3 * BM + tid) * 2];
-      const float sq = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1] + red[(2 * BM + tid) * 2 + 1] + red[(3 * BM + tid) * 2 + 1];
-      const long long m = mbase + tid;
+    if (tid < BM && tileM * BM + tid < p.DK) {
+      float sm = red[tid * 2], sq = red[tid * 2 + 1];
+      if (WN == 2) { sm += red[(BM + tid) * 2]; sq += red[(BM + tid) * 2 + 1]; }
+      const long long m = tileM * BM + tid;
       psum[m * p.P + tileN] = sm;
       psq[m * p.P + tileN] = sq;
     }
@@ -268,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void conv_stem_kernel(
 namespace gca_conv {
 
 size_t stem_lds_bytes(const StemParams& sp, int math) {
-  const size_t hrow = (size_t)4 * nparts(math) * sp.wp * 2;
-  return (size_t)sp.rowoff_bytes + 2 * 64 * pitchb(math) + (size_t)sp.g.SC * sp.hd * sp.hh * hrow;
+  const size_t halo = (size_t)sp.g.SC * sp.hd * sp.hh * sp.hrowb;
+  return (size_t)sp.rowoff_bytes + (halo > 2048 ? halo : 2048);
 }
 
 int stem_launch(int math, const StemParams& sp, const void* src, const unsigned char* apack, const float* bias, void* dst,
@@ -277,16 +283,17 @@ int stem_launch(int math, const StemParams& sp, const void* src, const unsigned 
   const size_t lds = stem_lds_bytes(sp, math);
   const long long nblk = (long long)sp.g.tilesM * sp.g.tilesN;
   if (nblk <= 0 || nblk > 0x7fffffffLL || lds > (size_t)(160 << 10) - 1024) return GCA_EINVAL;
-  static bool raised[4] = {false, false, false, false};
-#define GCA_SK(M)                                                                                                          \
+  static bool raised[4][2] = {};
+#define GCA_SK2(M, W)                                                                                                      \
   {                                                                                                                        \
-    if (lds > (48u << 10) && !raised[M]) {                                                                                 \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_kernel<M>),                                         \
+    if (lds > (48u << 10) && !raised[M][W / 4]) {                                                                          \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_stem_kernel<M, W>),                                      \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) != hipSuccess) return GCA_ELAUNCH;   \
-      raised[M] = true;                                                                                                    \
+      raised[M][W / 4] = true;                                                                                             \
     }                                                                                                                      \
-    hipLaunchKernelGGL((conv_stem_kernel<M>), dim3((unsigned)nblk), dim3(256), lds, st, src, apack, bias, dst, psum, psq, sp); \
+    hipLaunchKernelGGL((conv_stem_kernel<M, W>), dim3((unsigned)nblk), dim3(256), lds, st, src, apack, bias, dst, psum, psq, sp); \
   }
+#define GCA_SK(M) { if (sp.wm == 4) GCA_SK2(M, 4) else GCA_SK2(M, 2) }
   switch (math) {
     case 1: GCA_SK(1) break;
     case 2: GCA_SK(2) break;
@@ -294,6 +301,7 @@ int stem_launch(int math, const StemParams& sp, const void* src, const unsigned 
     default: return GCA_EINVAL;
   }
 #undef GCA_SK
+#undef GCA_SK2
   return gca_launch_status();
 }
 

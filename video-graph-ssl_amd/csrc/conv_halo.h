@@ -31,18 +31,20 @@ struct HaloCfg {
 // and <= 8 taps along W.
 struct StemParams {
   IgemmParams g;
-  int bd, bh, bw, lbh, lbw;     // box of 128 output positions per tile, w fastest; powers of two
+  int wm;                       // wave rows: 2 (tile 64 x 256) or 4 (tile 128 x 128)
+  int bd, bh, bw, lbh, lbw;     // box of 256 / 128 output positions per tile, w fastest; powers of two
   int nbd, nbh, nbw;            // boxes per clip
   int hd, hh;                   // halo rows: (bd-1)*sd + kd, (bh-1)*sh + kh
   int wp;                       // elements of one phase-row copy: bw + 4 (even)
+  int cd, hrowb;                // LDS layout: dwords between the two copies of a phase row (16 mod 32), bytes of one halo row
   int sd, sh, pd, ph, pw;       // strides in d, h (2 in w), padding
   int kd, kh, kw;
   int nrows, nsteps;            // C*kd*kh reduction rows, two per step
   int Mrows;                    // rows of one packed A step
-  int rowoff_bytes;             // LDS bytes of the row-offset table (multiple of 16)
+  int rowoff_bytes;             // LDS bytes of the two tables (reduction-row offsets, halo-row origins; multiple of 16)
   unsigned cs_bytes;            // channel stride of x (bytes)
   unsigned pack_bytes;
-  gca_magic m_w2, m_hdh, m_hh;  // divisions of the staging loop: 2*wp, hd*hh, hh
+  gca_magic m_w2, m_hdh, m_hh;  // divisions of the staging loop: wp, hd*hh, hh
 };
 
 // One thread per (step, row, pair of k) of the halo pack (PackParams fmt 1) or of the stem pack (fmt 2: k = 8*half + e, half
