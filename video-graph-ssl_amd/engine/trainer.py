@@ -377,19 +377,32 @@ class SimSiamTrainer(_TrainerBase):
         self.model.train()
         self.use_graph = bool(use_graph)
         self._static, self._segments, self._packer, self.out = None, None, None, {}
+        self._buckets, self._planned, self._tape = None, False, None     # N > 1: gradient buckets (see MoCoTrainer)
+        self._reducer = par.BucketReducer(self.arena.grad, self.ctx)
 
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, upto=0):
+        """Forward, loss and the backward pass down to tape index `upto` (0 = all of it; N > 1 runs the rest in stages)."""
         self.optimizer.zero_grad()
         if self._packer is not None:
             self._packer.run()
         tape = Tape(True)
         lv = self.model.fwd(tape, Var(self._static))
-        tape.backward()
-        if self._packer is not None:
-            self._packer.release()
         self.out = dict(loss=lv.t)
+        tape.backward(upto)
+        self._tape = tape if upto > 0 else None
+        if upto == 0 and self._packer is not None:
+            self._packer.release()
+
+    def _bwd_stage(self, upto, last):
+        self._tape.backward(upto)
+        if last:
+            self._tape = None
+            if self._packer is not None:
+                self._packer.release()
 
     def _update(self):
+        if self.ctx.active:
+            ops.scale_(self.arena.grad, 1.0 / self.ctx.world)      # DDP's mean (the loss gradient is seeded inside the model)
         clip = None
         if self.clip is not None:                              # tools/train_video_contrast_dis.py:497-500
             clip = self.optimizer.clip_grad_norm(self.clip)
@@ -400,14 +413,46 @@ class SimSiamTrainer(_TrainerBase):
         if self._static is None or self._static.shape != images.shape:
             self._static = torch.empty_like(images)
             self._packer = None
-            self._segments = [_Graphed(self._fwd_bwd, self.use_graph), _Graphed(self._update, self.use_graph)]
+            self._segments = None
         self._static.copy_(images)
         self.optimizer._sync_tables()
-        self._segments[0].run()
-        if self.ctx.active:
-            par.allreduce_sum_(self.arena.grad, self.ctx)
-            ops.scale_(self.arena.grad, 1.0 / self.ctx.world)
-        self._segments[1].run()
+        if not self.ctx.active:
+            if self._segments is None:
+                self._segments = [_Graphed(self._fwd_bwd, self.use_graph), _Graphed(self._update, self.use_graph)]
+            self._segments[0].run()
+            self._segments[1].run()
+        else:
+            # staged backward, one graph segment per gradient bucket, all-reduce of a bucket overlapped with the stages
+            # below it (as MoCoTrainer.train_step); the first step runs un-staged with the gradient log on and plans the buckets
+            if self._segments is None:
+                pool = torch.cuda.graph_pool_handle() if self.use_graph else None
+                if self._buckets is None:
+                    self._buckets = [(0, 0, self.arena.total)]
+                bk = self._buckets
+                last = len(bk) - 1
+                segs = [_Graphed(lambda u=(0 if last == 0 else bk[0][0]): self._fwd_bwd(u), self.use_graph, pool)]
+                for i in range(1, len(bk)):
+                    segs.append(_Graphed(lambda u=(0 if i == last else bk[i][0]), l=(i == last): self._bwd_stage(u, l),
+                                         self.use_graph, pool))
+                segs.append(_Graphed(self._update, self.use_graph, pool))
+                self._segments = segs
+            bk = self._buckets
+            be = int(getattr(self, 'bucket_elems', BUCKET_ELEMS))
+            planning = len(bk) == 1 and not self._planned and 0 < be < self.arena.total
+            if planning:
+                self._planned = True
+                L.GRAD_LOG = []
+            for i, (_, lo, hi) in enumerate(bk):
+                self._segments[i].run()
+                self._reducer.launch(lo, hi)
+            self._reducer.wait()
+            self._segments[-1].run()
+            if planning:
+                log, L.GRAD_LOG = L.GRAD_LOG, None
+                self._buckets = self._buckets_from_log(self.arena, log)
+                for g in self._segments:
+                    g.release()
+                self._segments = None
         if self._packer is None:
             self._packer = BatchedPacker(self.model, (0, 1))
         return self.out

@@ -26,12 +26,15 @@ class DistCtx(object):
     each collective: that is how the N>1 code path is rehearsed with the gloo backend when the ranks share
     one GPU (tests/test_gpu_dist.py); production (backend "nccl" = RCCL) leaves it False."""
 
-    def __init__(self, rank=0, world=1, group=None, host_staged=False):
+    def __init__(self, rank=0, world=1, group=None, host_staged=False, force_active=False):
         self.rank, self.world, self.group, self.host_staged = rank, world, group, bool(host_staged)
+        # force_active: run the multi-GPU control flow (exchange, gathers, bucketed all-reduce, segment graphs) even at
+        # world size 1 -- how the RCCL branches are exercised on a one-GPU box (tests/test_gpu_dist.py)
+        self.force_active = bool(force_active)
 
     @property
     def active(self):
-        return self.world > 1
+        return self.world > 1 or self.force_active
 
 
 def shared_permutation(n, seed, step):
