@@ -126,6 +126,8 @@ def _sym(c, tail=0):
     """Kernel symbol for a gca_conv_kernel_cfg tuple {rows, cols, splits, classes | fast<<8 | vec<<10 | arithmetic<<12} and
     the plan's two-phase code (tune_*_tail: short-tile rows/32 | main column tiles<<8)."""
     vec, fast, math = c[1] == 256, (c[3] >> 8) & 3, (c[3] >> 12) & 3       # bit 10 only says the class COULD use float4 gathers
+    if (c[3] >> 17) & 1:                                                    # pointwise fp16 GEMM kernel (conv3d_pw.hip)
+        return 'conv_pw_f16_kernel'
     if (c[3] >> 16) & 1:                                                    # stem kernel (conv3d_stem.hip)
         return 'conv_stem_kernel<%d>' % math
     if (c[3] >> 14) & 1:                                                    # LDS-halo kernel (conv3d_halo.hip)

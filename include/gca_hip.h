@@ -68,7 +68,8 @@ typedef struct {
   int32_t tune_fwd_bm, tune_fwd_splits;       /* tile rows 32..160 (x128 columns), | 1024 = x256 columns with float4
                                                  gathers (pointwise-in-space convs only), | 2048 = LDS-halo kernel (tile
                                                  box in tune_*_box), 4096 | 64 = stem kernel (forward, C <= 4, stride 2
-                                                 and <= 8 taps along W; bf16x3 / bf16x6 / fp16 storage); split-K factor */
+                                                 and <= 8 taps along W; bf16x3 / bf16x6 / fp16 storage), 8192 | 128 =
+                                                 pointwise fp16 GEMM kernel (1x1x1, unit stride, act_f16); split-K factor */
   int32_t tune_dgrad_bm, tune_dgrad_splits;
   int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile shape index 1..10 (see gca_conv_wgrad_cfg), 0 = heuristic */
   int32_t tune_fwd_tail, tune_dgrad_tail;      /* two-phase launch: (short tile rows / 32) | (column tiles run with the tall
@@ -122,11 +123,11 @@ int gca_conv_table_build_host(const gca_conv_geom* g, int which, int32_t* table_
 int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g);
 /* Tooling: the launch configuration in force for which = 0 (fwd) / 1 (dgrad), first non-empty class:
  * out4 = {tile rows, tile columns, split-K factor, classes | tap-mask kind (0 none, 1: <=31 taps, 2: <=62)<<8 | float4-gather<<10 |
- *         arithmetic (0 f32, 1 bf16x3, 2 bf16x6, 3 fp16 MFMA)<<12 | LDS-halo kernel<<14 | fp16 storage<<15 | stem kernel<<16}. */
+ *         arithmetic (0 f32, 1 bf16x3, 2 bf16x6, 3 fp16 MFMA)<<12 | LDS-halo kernel<<14 | fp16 storage<<15 | stem kernel<<16 | pointwise fp16 GEMM kernel<<17}. */
 int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4);
 /* Signature of the packed-weight layout that pass `which` (0 fwd, 1 dgrad) reads under the launch configuration in force:
- * one octal digit per problem class (0 = k-major fp32 rows of the gather kernels, 4 + arithmetic = the LDS-halo layout,
- * 1..3 = the stem layout in that arithmetic).
+ * one hex digit per problem class (0 = k-major fp32 rows of the gather kernels, 4 + arithmetic = the LDS-halo layout,
+ * 1..3 = the stem layout in that arithmetic, 8 = fp16 [rows][channels] of the pointwise GEMM kernel).
  * A buffer packed by gca_conv_pack is valid exactly as long as this value does not change (the host re-packs when a
  * tune_* field moves it). */
 int64_t gca_conv_pack_layout(const gca_conv_geom* g, int which);

@@ -45,6 +45,8 @@ CONV_CASES = [
     ((2, 24, 5, 10, 10), 36, (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     ((4, 64, 1, 1, 1), 24, (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     ((2, 3, 8, 64, 64), 64, (7, 7, 7), (1, 2, 2), (3, 3, 3)),           # large enough for the stem kernel (conv3d_stem.hip)
+    ((3, 40, 2, 12, 12), 200, (1, 1, 1), (1, 1, 1), (0, 0, 0)),         # pointwise GEMM kernel (conv3d_pw.hip): channel and row tails
+    ((2, 512, 2, 16, 16), 96, (1, 1, 1), (1, 1, 1), (0, 0, 0)),         # ... 16 k-tiles, 4 position tiles per clip
 ]
 
 
@@ -77,6 +79,16 @@ def test_conv_f16_storage_vs_f32_of_rounded_operands(ops, shape, K, k, s, p):
     ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
     assert dw.dtype is torch.float32
     assert rel_err(dw, wr.grad) < TOL_F
+    if k == (1, 1, 1) and s == (1, 1, 1) and (shape[2] * shape[3] * shape[4]) % 8 == 0 and shape[2] * shape[3] * shape[4] >= 128:
+        assert (plan.cfg(0)[3] >> 17) & 1 and (plan.cfg(1)[3] >> 17) & 1              # the pointwise GEMM kernel ran both passes
+        for name in ('fwd', 'dgrad'):                                                 # ... and agrees with the gather kernels
+            setattr(plan.g, 'tune_%s_bm' % name, 64)
+        plan.refresh()
+        assert not (plan.cfg(0)[3] >> 17) & 1
+        y2, (ss2, sq2) = ops.conv_fwd(plan, xd, ops.conv_pack(plan, 0, wd), None, stats=True)
+        dx2 = ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd))
+        assert rel_err(y.float(), y2.float()) < TOL_H and rel_err(dx.float(), dx2.float()) < TOL_H
+        assert rel_err(ss.sum(1), ss2.sum(1)) < 1e-3 and rel_err(sq.sum(1), sq2.sum(1)) < TOL_F
     # a plan built for one storage type refuses the other instead of misreading it
     with pytest.raises(TypeError):
         ops.conv_fwd(plan, x.to(DEV), ops.conv_pack(plan, 0, wd))

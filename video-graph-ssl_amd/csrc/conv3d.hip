@@ -883,6 +883,31 @@ inline bool halo_heuristic_on() {
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// ---- pointwise fp16 GEMM kernel (conv3d_pw.hip): 1x1x1, unit stride, no padding, fp16 storage, positions % 8 == 0 ---------
+// GCA_PW=0 keeps un-tuned pointwise convs on the gather kernels (the forced tune code 8192 is still honoured)
+inline bool pw_heuristic_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GCA_PW"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on != 0;
+}
+inline bool pw_geometry(const gca_conv_geom* g, int which, const IgemmParams& ip, PwParams& pw) {
+  if (!g->act_f16 || g->kd != 1 || g->kh != 1 || g->kw != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1 || g->pd || g->ph || g->pw)
+    return false;
+  const long long SP = (long long)g->D * g->H * g->W;
+  if (SP % 8 != 0 || SP < 128 || g->x_batch_stride % 8 != 0) return false;
+  const int Kc = which == 0 ? g->C : g->K, DK = which == 0 ? g->K : g->C;
+  pw.DK = DK; pw.Kc = Kc; pw.Kpad = (int)gca_round_up(Kc, 32);
+  pw.SP = (int)SP; pw.N = g->N;
+  pw.tilesM = cdiv(DK, 128); pw.tiles_sp = cdiv((int)SP, 128);
+  pw.P = g->N * pw.tiles_sp;
+  pw.accumulate = ip.accumulate;
+  pw.src_nstride = (unsigned)ip.src_nstride;
+  pw.src_bytes = ip.src_bytes; pw.dst_bytes = ip.dst_bytes;
+  const long long pb = (long long)pack_rows(DK) * pw.Kpad * 2;
+  pw.pack_bytes = pb > 0xfffff000LL ? 0xfffff000u : (unsigned)pb;
+  return true;
+}
+
 // LDS layout of a stem halo row (conv3d_stem.hip): [phase][part][copy][cd dwords].  (Measured and not kept: cd = 16 (mod 32)
 // with a row pitch of bw/2 (mod 32) dwords per output row, which makes every 32-lane read group conflict-free on paper --
 // the 2.7x larger rows cost more in occupancy and box shape than the conflicts do: 0.64 vs 0.66 ms on the R(2+1)D-18 stem
@@ -1009,12 +1034,18 @@ inline IgemmCfg cfg_for(const gca_conv_geom* g, int which, const ClassInfo& c, c
       return IgemmCfg{32 * sp.wm, 512 / sp.wm, 1, sp.nsteps, 0, 0, math, 2, sp.bd, sp.bh, sp.bw, math == 3};
   }
   if (fbm & 4096) { fbm = 0; fs = 0; tail = 0; }           // not runnable as asked
+  // ---- pointwise fp16 GEMM kernel: forced by tune code 8192, or by the heuristic when un-tuned
+  if ((fbm & 8192) || (fbm == 0 && pw_heuristic_on())) {
+    PwParams pw;
+    if (pw_geometry(g, which, p, pw)) return IgemmCfg{128, 128, 1, pw.Kpad / 32, 0, 0, 3, 3, 0, 0, 0, 1};
+  }
+  if (fbm & 8192) { fbm = 0; fs = 0; tail = 0; }
   // ---- LDS-halo kernel: forced by the tune code, or by the heuristic for multi-tap classes with enough channels and tiles
   {
     int bd = box & 255, bh = (box >> 8) & 255, bw = (box >> 16) & 255, rows = fbm & 1023;
     bool use = false;
     HaloParams hp;
-    if ((fbm & 2048) && !(fbm & 4096)) {
+    if ((fbm & 2048) && !(fbm & (4096 | 8192))) {
       use = bd > 0 && halo_geometry(c, p, bd, bh, bw, math, hp);
     } else if (fbm == 0 && halo_heuristic_on() && (c.ntaps >= 3 || math == 3) && c.srcC >= 32 && p.Ntot >= 128LL * 192) {
       double cost = 0, cost2 = 0;
@@ -1201,6 +1232,14 @@ int run_class_halo(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& c
   return gca_launch_status();
 }
 
+// A pointwise class on the fp16 GEMM kernel.
+int run_class_pw(const gca_conv_geom* g, int which, const float* src, const float* apack, const float* bias, float* dst, float* psum,
+                 float* psq, const IgemmParams& p, hipStream_t st) {
+  PwParams pw;
+  if (!pw_geometry(g, which, p, pw)) return GCA_EINVAL;
+  return pw_launch(pw, src, reinterpret_cast<const unsigned char*>(apack), bias, dst, psum, psq, st);
+}
+
 // The forward class on the stem kernel.
 int run_class_stem(const gca_conv_geom* g, const IgemmCfg& cf, const float* src, const float* apack, const float* bias, float* dst,
                    float* psum, float* psq, const IgemmParams& p, hipStream_t st) {
@@ -1248,7 +1287,7 @@ int conv_math() {
 
 extern "C" {
 
-int gca_version(void) { return 10; }
+int gca_version(void) { return 11; }
 
 int gca_set_conv_math(int mode) {
   if (mode < 0 || mode > 2) return GCA_EINVAL;
@@ -1274,7 +1313,8 @@ static void pack_params_of(const gca_conv_geom* g, int which, const ClassInfo& c
     const IgemmCfg cf = cfg_for(g, which, c, ip, nclasses);
     p.fmt = cf.halo; p.math = cf.math; p.SC = c.srcC; p.nsteps = cf.halo == 2 ? cf.kt_per_split : cdiv(c.srcC, 16) * c.ntaps;
   }
-  p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = (int)c.Kpad; p.Mrows = pack_rows(c.M);
+  const bool pwfmt = p.fmt == 3;
+  p.Kred = (int)c.Kred; p.M = c.M; p.Kpad = pwfmt ? (int)gca_round_up(c.srcC, 32) : (int)c.Kpad; p.Mrows = pack_rows(c.M);
   p.ntaps = p.fmt == 2 ? g->kd * g->kh : c.ntaps; p.nb = c.nb; p.nc = c.nc;       // (stem pack: reduction rows per channel)
   p.k0d = c.k0[0]; p.k0h = c.k0[1]; p.k0w = c.k0[2]; p.sd = c.ks[0]; p.sh = c.ks[1]; p.sw = c.ks[2];
   p.KH = g->kh; p.KW = g->kw; p.T = T;
@@ -1414,11 +1454,12 @@ int64_t gca_conv_pack_layout(const gca_conv_geom* g, int which) {
       IgemmParams p{};
       class_params(g, which, c, p);
       const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-      if (cf.halo == 2) code = cf.math;             // stem layout (arithmetic 1..3)
+      if (cf.halo == 3) code = 8;                   // pointwise fp16 GEMM operand
+      else if (cf.halo == 2) code = cf.math;        // stem layout (arithmetic 1..3)
       else if (cf.halo) code = 4 + cf.math;
     }
-    sig = sig * 8 + code;
-    if (sig > (1LL << 56)) sig %= 1000000007LL;    // (more than 18 classes: a hash is enough)
+    sig = sig * 16 + code;
+    if (sig > (1LL << 56)) sig %= 1000000007LL;    // (more than 14 classes: a hash is enough)
   }
   return sig;
 }
@@ -1432,7 +1473,7 @@ int gca_conv_kernel_cfg(const gca_conv_geom* g, int which, int32_t* out4) {
     IgemmParams p{};
     class_params(g, which, c, p);
     const IgemmCfg cf = cfg_for(g, which, c, p, cls.size());
-    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | ((cf.halo == 1) << 14) | (cf.h << 15) | ((cf.halo == 2) << 16);
+    out4[0] = cf.bm; out4[1] = cf.bn; out4[2] = cf.splits; out4[3] = (int)cls.size() | (fast_of(c.ntaps) << 8) | (c.vec << 10) | (cf.math << 12) | ((cf.halo == 1) << 14) | (cf.h << 15) | ((cf.halo == 2) << 16) | ((cf.halo == 3) << 17);
     return GCA_OK;
   }
   return GCA_EINVAL;
@@ -1445,6 +1486,7 @@ int64_t gca_conv_fwd_stat_parts(const gca_conv_geom* g) {
   IgemmParams p{};
   class_params(g, 0, cls[0], p);
   const IgemmCfg cf = cfg_for(g, 0, cls[0], p, 1);
+  if (cf.halo == 3) return (int64_t)g->N * cdiv((int)((long long)g->OD * g->OH * g->OW), 128);
   return stat_parts(cf, p.Ntot, cf.halo ? halo_tiles_n(g, cls[0], cf) : 0);
 }
 
@@ -1465,6 +1507,7 @@ int gca_conv_fwd(const gca_conv_geom* g, const void* x_, const float* wpack, con
   class_params(g, 0, c, p);
   p.accumulate = 0;
   const IgemmCfg cf = cfg_for(g, 0, c, p, 1);
+  if (cf.halo == 3) return run_class_pw(g, 0, x, wpack, bias, y, stat_sum, stat_sq, p, (hipStream_t)stream);
   if (cf.halo == 2) return run_class_stem(g, cf, x, wpack, bias, y, stat_sum, stat_sq, p, (hipStream_t)stream);
   if (cf.halo)
     return run_class_halo(g, c, cf, x, wpack, reinterpret_cast<const int2*>(table), bias, y, stat_sum, stat_sq,
@@ -1499,7 +1542,8 @@ int gca_conv_dgrad(const gca_conv_geom* g, const void* dy_, const float* wpack, 
     class_params(g, 1, c, p);
     p.accumulate = accumulate ? 1 : 0;
     const IgemmCfg cf = cfg_for(g, 1, c, p, cls.size());
-    int rc = cf.halo ? run_class_halo(g, c, cf, dy, wpack + c.pack_off, tab + c.table_off, nullptr, dx, nullptr, nullptr,
+    int rc = cf.halo == 3 ? run_class_pw(g, 1, dy, wpack + c.pack_off, nullptr, dx, nullptr, nullptr, p, st)
+           : cf.halo ? run_class_halo(g, c, cf, dy, wpack + c.pack_off, tab + c.table_off, nullptr, dx, nullptr, nullptr,
                                       reinterpret_cast<float*>(ws), p, st)
                      : run_class(cf, fast_of(c.ntaps), dy, wpack + c.pack_off,
                                  tab + c.table_off, nullptr, dx, nullptr, nullptr, reinterpret_cast<float*>(ws), p, st);

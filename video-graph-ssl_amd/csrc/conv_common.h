@@ -96,7 +96,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   const long long in_elems = (long long)g->N * (g->x_batch_stride ? g->x_batch_stride : cdhw);
   const long long out_elems = (long long)g->N * g->K * od * oh * ow;
   if (in_elems >= (1LL << 30) || out_elems >= (1LL << 30)) return false;
-  for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && ((v >> 10) <= 2 || (v >> 10) == 4))) return false;   // | 1024 float4 gathers, | 2048 LDS halo, | 4096 stem
+  for (int v : {g->tune_fwd_bm, g->tune_dgrad_bm}) if (v != 0 && !((v & 1023) % 32 == 0 && (v & 1023) >= 32 && (v & 1023) <= 160 && ((v >> 10) <= 2 || (v >> 10) == 4 || (v >> 10) == 8))) return false;   // | 1024 float4 gathers, | 2048 LDS halo, | 4096 stem, | 8192 pointwise fp16 GEMM
   for (int v : {g->tune_fwd_box, g->tune_dgrad_box}) if (v < 0 || v > 0xffffff) return false;
   if (g->act_f16 != 0 && g->act_f16 != 1) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;

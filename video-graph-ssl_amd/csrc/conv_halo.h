@@ -51,6 +51,20 @@ struct StemParams {
 // -> reduction row (c, kd-tap, kh-tap) = 2*step + half, e -> kw-tap 0,2,4,6 | 1,3,5,7; taps >= KW and rows past the end are 0).
 __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, unsigned char* __restrict__ packed,
                                                    const PackParams& p, long long first, long long step, long long end) {
+  if (p.fmt == 3) {                              // pointwise fp16 GEMM operand: [Mrows][Kpad] halves, k = reduction channel, contiguous
+    const int kp2 = p.Kpad >> 1;                 // (items: one per pair of k)
+    for (long long i = first; i < end; i += step) {
+      const int m = (int)(i / kp2), k = 2 * (int)(i - (long long)m * kp2);
+      float v0 = 0.f, v1 = 0.f;
+      if (m < p.M) {
+        if (k < p.SC) v0 = w[(long long)k * p.s_ch + (long long)m * p.s_m];
+        if (k + 1 < p.SC) v1 = w[(long long)(k + 1) * p.s_ch + (long long)m * p.s_m];
+      }
+      const unsigned lo = __builtin_bit_cast(unsigned short, (_Float16)v0), hi = __builtin_bit_cast(unsigned short, (_Float16)v1);
+      reinterpret_cast<unsigned*>(packed)[i] = lo | (hi << 16);
+    }
+    return;
+  }
   const int rowbytes = p.math == 3 ? 32 : (p.math == 2 ? 96 : 64);
   for (long long i = first; i < end; i += step) {
     const int kp = (int)(i & 7);                 // channel pair inside the chunk
@@ -95,6 +109,19 @@ __device__ __forceinline__ void pack_halo_elements(const float* __restrict__ w, 
     }
   }
 }
+
+// Kernel parameter block of conv_pw_f16_kernel (conv3d_pw.hip): pointwise conv on fp16 maps = one GEMM per clip.
+struct PwParams {
+  int DK, Kc, Kpad;             // output channels, reduction channels, reduction padded to 32 (packed row length)
+  int SP, N;                    // positions per clip (multiple of 8), clips
+  int tilesM, tiles_sp;         // row tiles of 128, column tiles of 128 per clip
+  int P;                        // BatchNorm partials per channel = N * tiles_sp
+  int accumulate;
+  unsigned src_nstride;         // elements between clips of the source
+  unsigned src_bytes, dst_bytes, pack_bytes;
+};
+int pw_launch(const PwParams& p, const void* src, const unsigned char* apack, const float* bias, void* dst, float* psum,
+              float* psq, hipStream_t st);
 
 size_t stem_lds_bytes(const StemParams& sp, int math);
 int stem_launch(int math, const StemParams& sp, const void* src, const unsigned char* apack, const float* bias, void* dst,

@@ -170,6 +170,7 @@ struct PackParams {
 };
 // work items of a pack job: fmt 0 one per packed float, fmt 1 one per (step, row, channel pair)
 __host__ __device__ inline long long pack_items(const PackParams& p) {
+  if (p.fmt == 3) return (long long)p.Mrows * (p.Kpad >> 1);      // pointwise fp16 operand: one item per pair of k
   return p.fmt >= 1 ? (long long)p.nsteps * p.Mrows * 8 : (long long)p.Mrows * p.Kpad;
 }
 

@@ -316,9 +316,13 @@ class ConvPlan:
             cands += self._halo_candidates(0, K)
             if g.C <= 4 and g.sw == 2 and g.kw <= 8:
                 cands.append((4096 | 64, 1, 0))                   # stem kernel (conv3d_stem.hip), box by its own heuristic
+            if g.act_f16 and self.taps == 1:
+                cands.append((8192 | 128, 1, 0))                  # pointwise fp16 GEMM kernel (conv3d_pw.hip)
         elif which == 1:
             cands = [c + (0,) for c in self._igemm_candidates(g.C, g.N * g.D * g.H * g.W, K * self.taps)]
             cands += self._halo_candidates(1, g.C)
+            if g.act_f16 and self.taps == 1:
+                cands.append((8192 | 128, 1, 0))
         else:
             cands = self._wgrad_candidates(K, g.C * self.taps, -(-(N * OD * OH * OW) // 32))
         # The arithmetic mode is a floor on accuracy: a pass may run a MORE accurate kernel when that one is faster
@@ -333,7 +337,8 @@ class ConvPlan:
                 return None
             if which < 2:
                 kc = self.cfg(which)[3]
-                if bool(c[0] & 2048) != bool((kc >> 14) & 1) or bool(c[0] & 4096) != bool((kc >> 16) & 1):
+                if (bool(c[0] & 2048) != bool((kc >> 14) & 1) or bool(c[0] & 4096) != bool((kc >> 16) & 1)
+                        or bool(c[0] & 8192) != bool((kc >> 17) & 1)):
                     return None                                   # halo / stem kernel asked for but not runnable here (or vice versa)
                 if layout() != packed_as[0]:
                     if repack is None:
