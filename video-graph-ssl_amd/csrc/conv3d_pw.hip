@@ -11,7 +11,10 @@
 //     that recipe for 256-byte rows, so stores and transposed reads are both conflict-free;
 //   * A = the weights packed fp16 [rows][channels] (pack fmt 3, k contiguous): 16-byte copies, ds_read_b128 fragments;
 //   * v_mfma_f32_32x32x16_f16, 128 x 128 tile, waves 2 x 2 (64 x 64 each), double-buffered LDS, one barrier per 32 channels;
-//   * epilogue as in the other conv kernels (buffer stores, accumulate, BatchNorm partial sums).
+//   * epilogue as in the other conv kernels (buffer stores, accumulate, BatchNorm partial sums).  (Measured and not kept: the
+//     output tile staged through LDS and written as 16-byte row segments -- no faster, 0.210 vs 0.217 ms on the 64 -> 256
+//     layer-1 conv, slower on the small maps: with 2..64 k-tiles per workgroup the kernel is bound by the latency of its
+//     one-tile-ahead operand fetch, not by its stores.)
 #include <cstring>
 #include "conv_igemm_host.h"
 #include "conv_halo.h"
