@@ -14,7 +14,8 @@
 //   * epilogue as in the other conv kernels (buffer stores, accumulate, BatchNorm partial sums).  (Measured and not kept: the
 //     output tile staged through LDS and written as 16-byte row segments -- no faster, 0.210 vs 0.217 ms on the 64 -> 256
 //     layer-1 conv, slower on the small maps: with 2..64 k-tiles per workgroup the kernel is bound by the latency of its
-//     one-tile-ahead operand fetch, not by its stores.)
+//     one-tile-ahead operand fetch, not by its stores; fetching TWO tiles ahead through a second register set costs a
+//     resident workgroup (193 VGPRs) and was slower still, 0.240 ms.)
 #include <cstring>
 #include "conv_igemm_host.h"
 #include "conv_halo.h"
