@@ -244,6 +244,10 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
   // while this chunk was being multiplied -- is split and written over the current one.
   // (Measured and not kept: three A buffers with the fragments of step s+1 read during the MFMAs of step s and the halo
   // re-staged inside the last step -- 40 more VGPRs, 50 % more LDS for A, 5-10 % slower on every layer shape.)
+  // (Also measured and not kept: for tiles of <= 64 rows, A fragments straight from the L2-resident packed weights, one step
+  // ahead in registers -- no LDS copy of A, no barrier per step.  Every one of the four waves then pulls the whole A tile
+  // through the L1: 155 vs 160 TF/s on the 64 x 256 bf16x6 tile, 23.1 vs 22.7 ms per step.  It pays in conv3d_stem.hip, whose
+  // waves split the rows.)
   const int c0 = split * hp.chunks_per_split;
   int c1 = c0 + hp.chunks_per_split; if (c1 > hp.nchunks) c1 = hp.nchunks;
   const int nt = p.ntaps;
