@@ -177,6 +177,7 @@ def test_bn_f16_storage_vs_f32_kernels(ops, shape, res):
 
 
 @pytest.mark.parametrize('shape,k,s,p', [((2, 5, 8, 18, 18), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+                                         ((2, 4, 6, 20, 24), (3, 3, 3), (2, 2, 2), (1, 1, 1)),       # LDS-tiled backward
                                          ((2, 4, 3, 9, 10), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
                                          ((1, 3, 4, 6, 6), (2, 2, 2), (2, 2, 2), (0, 0, 0)),
                                          ((1, 2, 5, 7, 9), (3, 2, 1), (1, 1, 1), (1, 1, 0))])

@@ -615,7 +615,9 @@ def test_gather_rows_contiguous_and_batch_strided_view(ops):
 
 
 @pytest.mark.parametrize('shape,k,s,p', [
-    ((2, 5, 9, 14, 15), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # R(2+1)D / 3D-ResNet stem pool (unrolled 3x3x3, cover 2x2x2)
+    ((2, 5, 9, 14, 15), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # R(2+1)D / 3D-ResNet stem pool (W % 4 != 0: per-element backward)
+    ((2, 5, 9, 14, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # ... LDS-tiled backward, ragged boxes in D and H
+    ((1, 3, 8, 40, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # ... several boxes per plane in every dimension
     ((2, 3, 4, 13, 11), (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # S3D spatial pools
     ((2, 3, 5, 7, 9), (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # S3D Mixed_* branch pool (cover 3x3x3)
     ((2, 3, 6, 8, 10), (2, 2, 2), (2, 2, 2), (0, 0, 0)),      # non-overlapping
@@ -695,6 +697,15 @@ def test_maxpool_with_fused_bn_relu_producer(ops):
         y0, a0 = ops.maxpool_fwd(plan, z)
         y1, a1 = ops.maxpool_fwd(plan, x, True, sc, sh)
         assert torch.equal(y0, y1) and torch.equal(a0, a1)
+    # at a size with many blocks: fused producer == pooling the materialised tensor == ATen, bit for bit
+    x = torch.randn(2, 4, 12, 44, 52, device=DEV)
+    sc, sh = torch.randn(4, device=DEV), torch.randn(4, device=DEV)
+    z = ops.bn_apply(x, sc, sh, None, True, 2, 4, 12 * 44 * 52)
+    plan = ops.pool_plan(tuple(x.shape), (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    y0, a0 = ops.maxpool_fwd(plan, z)
+    y1, a1 = ops.maxpool_fwd(plan, x, True, sc, sh)
+    yr, ir = F.max_pool3d(z.cpu(), 3, 2, 1, return_indices=True)
+    assert torch.equal(y0, y1) and torch.equal(a0, a1) and torch.equal(y0.cpu(), yr) and torch.equal(a0.cpu().long(), ir)
 
 
 def test_autotuner_pins_a_valid_configuration(ops):
