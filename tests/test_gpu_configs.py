@@ -282,14 +282,19 @@ def test_workspace_growth_keeps_captured_graphs_valid(pkg):
     b = pkg.MoCoTrainer(cfg, DEV, use_graph=True, seed=9)
     for i in range(3):                                     # eager, eager, capture + replay
         a.train_step(xs[i], shs[i]); b.train_step(xs[i], shs[i])
-    key = (DEV.type, DEV.index)
-    before = ops.WS.buf[key]
-    assert key in ops.WS.captured
-    # a large eager user of the workspace: BatchNorm backward partials of a big tensor + a wide InfoNCE
-    big = ops.WS.get(before.numel() * 3 + (64 << 20), DEV)
-    assert big.data_ptr() != before.data_ptr() and any(r is before for r in ops.WS.retired)
-    big.fill_(0x7f)                                        # scribble over the NEW buffer; the graph must not care
-    torch.empty(before.numel(), dtype=torch.uint8, device=DEV).fill_(0x55)   # and whatever the allocator hands out next
+    for lane in (0, 1):                                    # lane 1 = the key encoder's scratch (second stream of the captured step)
+        key = (DEV.type, DEV.index, lane)
+        before = ops.WS.buf[key]
+        assert key in ops.WS.captured
+        # a large eager user of the workspace: BatchNorm backward partials of a big tensor + a wide InfoNCE
+        ops.WS_LANE[0] = lane
+        try:
+            big = ops.WS.get(before.numel() * 3 + (64 << 20), DEV)
+        finally:
+            ops.WS_LANE[0] = 0
+        assert big.data_ptr() != before.data_ptr() and any(r is before for r in ops.WS.retired)
+        big.fill_(0x7f)                                    # scribble over the NEW buffer; the graph must not care
+        torch.empty(before.numel(), dtype=torch.uint8, device=DEV).fill_(0x55)   # and whatever the allocator hands out next
     torch.cuda.synchronize()
     for i in (3, 4):
         oa, ob = a.train_step(xs[i], shs[i]), b.train_step(xs[i], shs[i])

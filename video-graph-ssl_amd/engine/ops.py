@@ -37,7 +37,7 @@ class _Workspace:
         self.retired = []
 
     def get(self, nbytes, device):
-        key = (device.type, device.index)
+        key = (device.type, device.index, WS_LANE[0])
         b = self.buf.get(key)
         capturing = torch.cuda.is_current_stream_capturing()
         if b is None or b.numel() < nbytes:
@@ -54,6 +54,9 @@ class _Workspace:
         return b
 
 
+# Scratch lane: work issued on a second stream next to the main one (the key encoder's forward inside the captured
+# single-GPU step, engine/trainer.py) takes its scratch from its own buffer -- lanes never share split-K slabs.
+WS_LANE = [0]
 WS = _Workspace()
 
 

@@ -101,6 +101,8 @@ def _check_unsupported(cfg):
                                   'select the reduced-precision conv path with engine.ops.set_conv_math instead')
 
 
+# GCA_FORK_KEY=0: key and query encoders on one stream inside the captured step as well (A/B runs)
+FORK_KEY_ENCODER = os.environ.get('GCA_FORK_KEY', '1') != '0'
 # gradient all-reduce bucket: 8 M fp32 = 32 MB (four buckets for R(2+1)D-18 + head); 0 = one all-reduce after the backward pass
 BUCKET_ELEMS = int(os.environ.get('GCA_BUCKET_ELEMS', 8 << 20))
 
@@ -179,6 +181,7 @@ class MoCoTrainer(_TrainerBase):
         self._planned = False
         self._plans = None          # N > 1: look-ahead ShuffleBN exchange plans (parallel.ExchangePlans)
         self._reducer = par.BucketReducer(self.arena_q.grad, self.ctx)
+        self._side = None           # second stream of the captured single-GPU step (key encoder forward)
         self.out = {}
 
     # -------------------------------------------------------------------------------- buffers
@@ -218,15 +221,19 @@ class MoCoTrainer(_TrainerBase):
         self._unpack('k')
         s['k_shuf'].copy_(kv.t)
 
-    def _phase_query(self, upto=0):
-        """Query encoder forward, InfoNCE, enqueue, dq and the backward pass down to tape index `upto` (0 = all of it;
-        N > 1 runs the rest in stages, one per gradient bucket: _phase_backward_stage)."""
+    def _phase_query_fwd(self):
+        """Query encoder forward (needs nothing from the key encoder)."""
         s = self._static
-        b = s['images'].shape[0]
         self.optimizer.zero_grad()
         self._pack('q')
         tape = Tape(True)
         qv = self.model.fwd(tape, Var(torch.chunk(s['images'], 2, dim=1)[0]))
+        return tape, qv
+
+    def _phase_query_rest(self, tape, qv, upto=0):
+        """InfoNCE, enqueue, dq and the backward pass down to tape index `upto` (0 = all of it; N > 1 runs the rest in stages,
+        one per gradient bucket: _phase_backward_stage)."""
+        s = self._static
         mem = self.contrast.memory
         logits, lse, rank, loss = ops.moco_logits_fwd(qv.t, s['k'], mem, self.inv_T, want_lse=True, want_rank=True,
                                                       want_loss=True)
@@ -240,6 +247,10 @@ class MoCoTrainer(_TrainerBase):
         self._tape = tape if upto > 0 else None
         if upto == 0:
             self._unpack('q')
+
+    def _phase_query(self, upto=0):
+        tape, qv = self._phase_query_fwd()
+        self._phase_query_rest(tape, qv, upto)
 
     def _phase_backward_stage(self, upto, last):
         self._tape.backward(upto)
@@ -258,13 +269,33 @@ class MoCoTrainer(_TrainerBase):
         ops.ema_update(self.arena_k.flat, self.arena_q.flat, self.alpha)      # :440
 
     def _single_gpu_all(self):
+        """The whole N = 1 iteration.  Inside the captured hipGraph the key encoder's forward runs on a SECOND stream next
+        to the query encoder's forward (they share nothing until InfoNCE): the latency-bound kernels of the deep, small layers
+        of one encoder fill the CUs the other leaves idle.  Eager runs keep one stream (the launch tuner times kernels
+        there) but already use the key lane's own scratch buffer, so nothing grows during the capture."""
         s = self._static
-        self._phase_key()
+        fork = FORK_KEY_ENCODER and torch.cuda.is_current_stream_capturing()
+        ops.WS_LANE[0] = 1
+        try:
+            if fork:
+                cur = torch.cuda.current_stream()
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    self._phase_key()
+            else:
+                self._phase_key()
+        finally:
+            ops.WS_LANE[0] = 0
+        tape, qv = self._phase_query_fwd()
+        if fork:
+            cur.wait_stream(self._side)
         # N=1: BN batch statistics are permutation invariant, so the clips are NOT physically shuffled;
         # only the enqueue order (all_k = k in shuffled order, :222) is reproduced.
         s['k'].copy_(s['k_shuf'])
         s['all_k'].copy_(ops.gather_rows(s['k_shuf'], s['enq_idx']))
-        self._phase_query()
+        self._phase_query_rest(tape, qv, 0)
         self._phase_update()
 
     # -------------------------------------------------------------------------------- step
