@@ -181,7 +181,8 @@ class MoCoTrainer(_TrainerBase):
         self._planned = False
         self._plans = None          # N > 1: look-ahead ShuffleBN exchange plans (parallel.ExchangePlans)
         self._reducer = par.BucketReducer(self.arena_q.grad, self.ctx)
-        self._side = None           # second stream of the captured single-GPU step (key encoder forward)
+        self._side = None           # second stream of the captured step (key encoder forward)
+        self._fwd = None            # N > 1: (tape, query feature) between the forward segment and the rest
         self.out = {}
 
     # -------------------------------------------------------------------------------- buffers
@@ -248,10 +249,6 @@ class MoCoTrainer(_TrainerBase):
         if upto == 0:
             self._unpack('q')
 
-    def _phase_query(self, upto=0):
-        tape, qv = self._phase_query_fwd()
-        self._phase_query_rest(tape, qv, upto)
-
     def _phase_backward_stage(self, upto, last):
         self._tape.backward(upto)
         if last:
@@ -268,12 +265,12 @@ class MoCoTrainer(_TrainerBase):
         self.optimizer.step(grad_clip=clip)
         ops.ema_update(self.arena_k.flat, self.arena_q.flat, self.alpha)      # :440
 
-    def _single_gpu_all(self):
-        """The whole N = 1 iteration.  Inside the captured hipGraph the key encoder's forward runs on a SECOND stream next
-        to the query encoder's forward (they share nothing until InfoNCE): the latency-bound kernels of the deep, small layers
-        of one encoder fill the CUs the other leaves idle.  Eager runs keep one stream (the launch tuner times kernels
-        there) but already use the key lane's own scratch buffer, so nothing grows during the capture."""
-        s = self._static
+    def _key_and_query_fwd(self):
+        """Key encoder forward and query encoder forward (they share nothing until InfoNCE).  Inside a captured hipGraph the
+        key encoder runs on a SECOND stream next to the query encoder: the latency-bound kernels of the deep, small layers
+        of one fill the CUs the other leaves idle (measured +5 % on the whole step at N = 1).  Eager runs keep one stream (the
+        launch tuner times kernels there) but already use the key lane's own scratch buffer, so nothing grows during the
+        capture.  -> (tape, query feature Var)"""
         fork = FORK_KEY_ENCODER and torch.cuda.is_current_stream_capturing()
         ops.WS_LANE[0] = 1
         try:
@@ -291,12 +288,25 @@ class MoCoTrainer(_TrainerBase):
         tape, qv = self._phase_query_fwd()
         if fork:
             cur.wait_stream(self._side)
+        return tape, qv
+
+    def _single_gpu_all(self):
+        s = self._static
+        tape, qv = self._key_and_query_fwd()
         # N=1: BN batch statistics are permutation invariant, so the clips are NOT physically shuffled;
         # only the enqueue order (all_k = k in shuffled order, :222) is reproduced.
         s['k'].copy_(s['k_shuf'])
         s['all_k'].copy_(ops.gather_rows(s['k_shuf'], s['enq_idx']))
         self._phase_query_rest(tape, qv, 0)
         self._phase_update()
+
+    def _phase_fwd_pair(self):
+        """N > 1, first segment: both encoder forwards; the tape lives on until the next segment (after the key gather)."""
+        self._fwd = self._key_and_query_fwd()
+
+    def _phase_rest(self, upto):
+        (tape, qv), self._fwd = self._fwd, None
+        self._phase_query_rest(tape, qv, upto)
 
     # -------------------------------------------------------------------------------- step
     def train_step(self, images, shuffle_ids=None):
@@ -321,7 +331,7 @@ class MoCoTrainer(_TrainerBase):
                 self._plans = par.ExchangePlans(b, self.ctx, self.perm_seed, self.device)
             plan = self._plans.get(self.step_count, user_ids)
             if self._segments is None:
-                # One graph segment per stage: key forward | query forward + InfoNCE + backward down to the first bucket
+                # One graph segment per stage: key forward || query forward (two streams) | InfoNCE + backward down to the first bucket
                 # boundary | one backward stage per further gradient bucket | update.  The all-reduce of a bucket is
                 # issued behind the segment that completes it and runs on RCCL's stream while the next stage computes
                 # (DDP's overlap, tools/train_video_contrast_dis.py:143,419, with a few 32 MB buckets).  Activations
@@ -331,8 +341,8 @@ class MoCoTrainer(_TrainerBase):
                     self._buckets = [(0, 0, self.arena_q.total)]         # first step: un-staged; planned below
                 bk = self._buckets
                 last = len(bk) - 1
-                segs = [_Graphed(self._phase_key, self.use_graph, pool),
-                        _Graphed(lambda u=(0 if last == 0 else bk[0][0]): self._phase_query(u), self.use_graph, pool)]
+                segs = [_Graphed(self._phase_fwd_pair, self.use_graph, pool),
+                        _Graphed(lambda u=(0 if last == 0 else bk[0][0]): self._phase_rest(u), self.use_graph, pool)]
                 for i in range(1, len(bk)):
                     segs.append(_Graphed(lambda u=(0 if i == last else bk[i][0]), l=(i == last): self._phase_backward_stage(u, l),
                                          self.use_graph, pool))
