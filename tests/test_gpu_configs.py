@@ -6,6 +6,7 @@ library-level robustness cases (gradient clipping, workspace growth under captur
   configs[3]  the ASSEMBLED S3D + TemporalGraphAug (before base.5 / base.9 / base.14) + SimSiam heads model
               (visual_wrappers.py:113-124, lib/ops/build.py:9-32, graph_wrappers.py:48-71) against the oracle wrappers.
 """
+import importlib
 import os
 import subprocess
 import sys
@@ -302,6 +303,41 @@ def test_workspace_growth_keeps_captured_graphs_valid(pkg):
     for (n, p), (_, q) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
         assert torch.equal(p, q), n
     a.close(); b.close()
+
+
+def test_two_stream_captured_step_is_bit_identical_to_one_stream(pkg):
+    """Inside the captured hipGraph the key encoder's forward runs on a second stream next to the query encoder's (own
+    scratch lane, joined before InfoNCE).  Same kernels on the same operands: four steps (two eager, capture, replay) must
+    give bit-identical losses, logits and parameters with and without the fork."""
+    trainer_mod = importlib.import_module('video-graph-ssl_amd.engine.trainer')
+    parity.register_tiny(pkg)
+    cfg = parity.make_cfg(pkg, 'R2P1D10T', 'moco', 32, 20, 8)
+    gen = torch.Generator().manual_seed(5)
+    xs = [torch.randn(8, 6, 8, 48, 48, generator=gen).to(DEV) for _ in range(4)]
+    shs = [torch.randperm(8, generator=gen) for _ in range(4)]
+    runs = []
+    default = trainer_mod.FORK_KEY_ENCODER
+    try:
+        for fork in (True, False):
+            trainer_mod.FORK_KEY_ENCODER = fork
+            with pkg.MoCoTrainer(cfg, DEV, use_graph=True, seed=4) as tr:
+                outs = []
+                for x, sh in zip(xs, shs):
+                    o = tr.train_step(x, sh)
+                    outs.append((o['loss'].clone(), o['logits'].clone()))
+                torch.cuda.synchronize()
+                assert (tr._side is not None) == fork                     # the second stream really was used (or not)
+                runs.append((outs, {k: v.clone() for k, v in tr.model.state_dict().items()},
+                             {k: v.clone() for k, v in tr.model_ema.state_dict().items()}))
+    finally:
+        trainer_mod.FORK_KEY_ENCODER = default
+    (oa, pa, ka), (ob, pb, kb) = runs
+    for (la, ga), (lb, gb) in zip(oa, ob):
+        assert torch.equal(la, lb) and torch.equal(ga, gb)
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    for k in ka:
+        assert torch.equal(ka[k], kb[k]), k
 
 
 _EXIT_SCRIPT = r'''
