@@ -12,12 +12,14 @@
 // W phase (and into bf16 parts), each phase row twice -- as is and shifted by one element -- so that every lane's 4-element
 // run starts on a 4-byte boundary whatever the parity of its column:
 //
-//     Hs[(c, zd, zh)][phase][part][copy][wp (padded)]   16-bit elements
+//     Hs[(c, zd, zh)][phase][part][copy][wp]   16-bit elements
 //
 // and the B fragment of a k-step is two ds_read2_b32 per part (E run | O run) at  row(c,a,b) + lane position  -- no
 // per-element gathers, no operand split in the loop.  k = 7 (the pad of the odd run) multiplies a zero weight.  Weights are
 // packed [step][row][part][16] in the same k order, pre-split (conv_halo.h, fmt 2); two (c,a,b) rows per step (the lane
-// halves).  A tile is a box of 256 output positions x 64 output channels; epilogue as in conv3d_halo.hip.
+// halves); a wave owns one 32-row tile and reads its A fragments straight from the L2-resident pack, one step ahead -- no LDS
+// copy of the weights and no barrier in the k loop.  A tile is a box of 256 output positions x 64 output channels (waves
+// 2 x 2) or 128 positions x 128 channels (4 x 1, more than 64 output channels); epilogue as in conv3d_halo.hip.
 #include <cstring>
 #include "conv_igemm_host.h"
 #include "conv_halo.h"
