@@ -549,31 +549,58 @@ __global__ __launch_bounds__(256) void moco_dq_kernel(
   const int mt = blockIdx.z;
   const long long ld = K + 1;
   const float g = (gs_dev ? *gs_dev : 1.f) * gs_host / (float)b;
-  // stage G^T: lanes along j (coalesced), one batch row per step
-  for (int i = tid; i < 32 * BWD_RS; i += 256) {
-    const int m = i / BWD_RS, jj = i % BWD_RS;
-    const int row = mt * 32 + m;
-    const long long j = j0 + jj;
-    float v = 0.f;
-    if (row < b && j < K) {
-      if (dl) v = dl[(long long)row * ld + 1 + j];
-      else v = g * expf(logits[(long long)row * ld + 1 + j] - lse[row]);
+  // stage G^T: lanes along j (coalesced), one batch row per step; all 16 loads of a thread in flight (unconditional buffer
+  // loads: see below)
+  {
+    const float* gsrc = dl ? dl : logits;
+    const long long gb = (long long)b * ld * 4;
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gsrc), 0,
+                                                                        gb > 0xfffff000LL ? 0xfffff000u : (unsigned)gb, 0x00020000);
+    constexpr int NG = 32 * BWD_RS / 256;
+    float gv[NG];
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int i = tid + 256 * u;
+      const int m = i / BWD_RS, jj = i % BWD_RS;
+      const int row = mt * 32 + m;
+      const long long j = j0 + jj;
+      const bool ok = row < b && j < K;
+      gv[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, ok ? (int)(unsigned)(((long long)row * ld + 1 + j) * 4) : -1, 0, 0));
     }
-    Gs[jj][m] = v;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) {
+      const int i = tid + 256 * u;
+      const int m = i / BWD_RS, jj = i % BWD_RS;
+      const int row = mt * 32 + m;
+      const bool ok = row < b && j0 + jj < K;
+      float v = gv[u];
+      if (!dl) v = ok ? g * expf(v - lse[min(row, b - 1)]) : 0.f;
+      Gs[jj][m] = v;
+    }
   }
   __syncthreads();
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool dv = dcol < D;
-#pragma unroll 4
+  // UNCONDITIONAL loads through buffer resources (an out-of-range / not-wanted element is an all-ones offset the hardware
+  // zero-fills): a load inside a branch makes hipcc drain vmcnt(0) at every use, i.e. one exposed HBM round trip per row
+  // pair -- this loop took 154 us at K = 65536 that way.  Both candidates of a row (queue / saved pre-enqueue copy) are
+  // fetched, the copy's offset is valid only inside the overwritten window.
+  const unsigned qbytes = K * (long long)D * 4 > 0xfffff000LL ? 0xfffff000u : (unsigned)(K * D * 4);
+  const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(queue), 0, qbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ov_rows ? ov_rows : queue), 0,
+                                                                      ov_rows ? (unsigned)(ov_n * D * 4) : 0u, 0x00020000);
+#pragma unroll 8
   for (int kk = 0; kk < BWD_RS; kk += 2) {
     const long long j = j0 + kk + lh;
-    float bb = 0.f;
-    if (dv && j < K) {
-      long long rel = j - ov_start; if (rel < 0) rel += K;
-      bb = (rel < ov_n) ? ov_rows[rel * D + dcol] : queue[j * D + dcol];
-    }
+    long long rel = j - ov_start; if (rel < 0) rel += K;
+    const bool in = dv && j < K, ov = in && rel < ov_n;
+    const unsigned vq = in ? (unsigned)((j * D + dcol) * 4) : 0xffffffffu;
+    const unsigned vo = ov ? (unsigned)((rel * D + dcol) * 4) : 0xffffffffu;
+    const float qv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rq, (int)vq, 0, 0));
+    const float sv = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ro, (int)vo, 0, 0));
+    const float bb = ov ? sv : qv;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Gs[kk + lh][ll], bb, acc, 0, 0, 0);
   }
   if (dv) {
@@ -586,21 +613,44 @@ __global__ __launch_bounds__(256) void moco_dq_kernel(
   }
 }
 
+// dq[e] = (sum over slices of slab[k][e] + g0 * kpos[e]) / T.  A block finishes 16 elements: 16 groups of 16 threads each
+// sum the slices k = group, group + 16, ... (loads 8 deep in flight: the K = 65536 queue makes 512 slices, and one thread
+// walking all of them was 100+ us of exposed latency), then the 16 group sums are added in group order -- a fixed tree,
+// so the result is deterministic.
 __global__ __launch_bounds__(256) void moco_dq_finish_kernel(
     const float* __restrict__ slab, int slices, const float* __restrict__ dl, const float* __restrict__ logits,
     const float* __restrict__ lse, const float* __restrict__ gs_dev, float gs_host, const float* __restrict__ kpos,
     int b, long long K, int D, float inv_T, float* __restrict__ dq) {
+  __shared__ float part[16][17];
   const long long total = (long long)b * D;
   const long long ld = K + 1;
   const float g = (gs_dev ? *gs_dev : 1.f) * gs_host / (float)b;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long long e = (long long)blockIdx.x * 16 + el;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(slab), 0,
+                                                                      (unsigned)((long long)slices * total * 4), 0x00020000);
+  float s = 0.f;
+  for (int k0 = grp; k0 < slices; k0 += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 16 * u;
+      v[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (k < slices && e < total) ? (int)(unsigned)(((long long)k * total + e) * 4) : -1, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  part[grp][el] = s;
+  __syncthreads();
+  if (grp == 0 && e < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += part[q][el];
     const long long i = e / D;
-    float s = 0.f;
-    for (int k = 0; k < slices; ++k) s += slab[(long long)k * total + e];
     float g0;
     if (dl) g0 = dl[i * ld];
     else g0 = g * (expf(logits[i * ld] - lse[i]) - 1.f);
-    dq[e] = (s + g0 * kpos[e]) * inv_T;
+    dq[e] = (t + g0 * kpos[e]) * inv_T;
   }
 }
 
@@ -752,6 +802,7 @@ int gca_moco_logits_bwd(const float* dlogits, const float* logits, const float* 
   if (!dlogits && (!logits || !row_lse)) return GCA_EINVAL;
   if (ov_n < 0 || ov_n > K || (ov_n > 0 && !ov_rows) || ov_start < 0 || ov_start >= K) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
+  if (K * D * 4 >= 0xfffff000LL || b * (K + 1) * 4 >= 0xfffff000LL) return GCA_EINVAL;      // 32-bit byte offsets in the kernel
   const int slices = (int)gca_ceil_div(K, BWD_RS);
   float* slab = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)slices, (unsigned)gca_ceil_div(D, 128), (unsigned)gca_ceil_div(b, 32));
@@ -760,7 +811,7 @@ int gca_moco_logits_bwd(const float* dlogits, const float* logits, const float* 
                      slab);
   int rc = gca_launch_status();
   if (rc) return rc;
-  hipLaunchKernelGGL(moco_dq_finish_kernel, dim3((unsigned)gca_ceil_div(b * D, 256)), dim3(256), 0, st, slab, slices,
+  hipLaunchKernelGGL(moco_dq_finish_kernel, dim3((unsigned)gca_ceil_div(b * D, 16)), dim3(256), 0, st, slab, slices,
                      dlogits, logits, row_lse, gscale_dev, gscale_host, k, (int)b, (long long)K, (int)D, inv_T, dq);
   return gca_launch_status();
 }
