@@ -257,7 +257,8 @@ def pmc_traffic(symbol):
     (profiles/pmc_traffic.json, produced by tools/pmc_step.sh + tools/pmc_parse.py: separate FETCH_SIZE and
     WRITE_SIZE passes; gfx950 correction 2x FETCH_SIZE, calibrated in that file on the EMA/SGD kernels).
     None when the profile has no entry for this kernel (different launch configuration than profiled)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_traffic.json')
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
+                        'pmc_traffic_f16.json' if _MATH[0] == 3 else 'pmc_traffic.json')     # (the fp16-storage step has its own passes)
     try:
         with open(path) as f:
             prof = json.load(f)['kernels']
