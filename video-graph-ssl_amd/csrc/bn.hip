@@ -290,20 +290,41 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
   __syncthreads();
   const float sc = ab[0], sf = ab[1];
   const int per = SP / VEC, total = N * per;
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int n = i / per, sp = (i - n * per) * VEC;
-    const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
-    if (VEC == 4) {
-      float4 v = A_::ld4(x + xi);
-      v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
-      if (res) { const float4 r = A_::ld4(res + xi); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      A_::st4(z + zi, v);
-    } else {
-      float v = A_::ld(x + xi) * sc + sf;
-      if (res) v += A_::ld(res + xi);
-      if (relu) v = fmaxf(v, 0.f);
-      A_::st(z + zi, v);
+  // UF slots per thread per trip, all loads issued before the first use (clamped index: unconditional loads): a channel of
+  // these layers is 6-25 trips of 256 threads, and one exposed L2 round trip per trip was most of the kernel's 11 us
+  // (now 9.4; eight slots per trip measured no better: 10.4)
+  constexpr int UF = 4;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * UF) {
+    long long xi[UF], zi[UF];
+    float4 xv[UF], rv[UF];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      const int i = min(i0 + 256 * u, total - 1);
+      const int n = i / per, sp = (i - n * per) * VEC;
+      xi[u] = ((long long)n * C + c) * SP + sp; zi[u] = (long long)n * zs + (long long)c * SP + sp;
+      if (VEC == 4) {
+        xv[u] = A_::ld4(x + xi[u]);
+        if (res) rv[u] = A_::ld4(res + xi[u]);
+      } else {
+        xv[u].x = A_::ld(x + xi[u]);
+        if (res) rv[u].x = A_::ld(res + xi[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      if (i0 + 256 * u >= total) break;
+      if (VEC == 4) {
+        float4 v = xv[u];
+        v.x = v.x * sc + sf; v.y = v.y * sc + sf; v.z = v.z * sc + sf; v.w = v.w * sc + sf;
+        if (res) { const float4 r = rv[u]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        A_::st4(z + zi[u], v);
+      } else {
+        float v = xv[u].x * sc + sf;
+        if (res) v += rv[u].x;
+        if (relu) v = fmaxf(v, 0.f);
+        A_::st(z + zi[u], v);
+      }
     }
   }
 }
@@ -325,22 +346,34 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
   const float rsc = relu == 2 ? scale[c] : 0.f, rsf = relu == 2 ? shift[c] : 0.f;
   const int per = SP / VEC, total = N * per;                 // VEC-wide slots of this channel
   double s0 = 0.0, s1 = 0.0;
-  for (int i = threadIdx.x; i < total; i += 256) {
+  // UF slots per thread per trip with every load issued before the first use (clamped index: unconditional loads): one
+  // exposed round trip per 256-thread trip was most of this kernel's 17-20 us
+  constexpr int UF = 4;
+  auto load_slot = [&](int i, long long& xi, long long& zi, float (&dv)[VEC], float (&xv)[VEC], float (&zv)[VEC]) __attribute__((always_inline)) {
     const int n = i / per, sp = (i - n * per) * VEC;
-    const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
-    float dv[VEC], xv[VEC], zv[VEC];
+    xi = ((long long)n * C + c) * SP + sp; zi = (long long)n * zs + (long long)c * SP + sp;
     if (VEC == 4) {
       const float4 d4 = A_::ld4(dzin + zi), x4 = A_::ld4(x + xi);
       dv[0] = d4.x; dv[VEC > 1 ? 1 : 0] = d4.y; dv[VEC > 2 ? 2 : 0] = d4.z; dv[VEC > 3 ? 3 : 0] = d4.w;
       xv[0] = x4.x; xv[VEC > 1 ? 1 : 0] = x4.y; xv[VEC > 2 ? 2 : 0] = x4.z; xv[VEC > 3 ? 3 : 0] = x4.w;
       if (relu == 1) { const float4 z4 = A_::ld4(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
     } else { dv[0] = A_::ld(dzin + zi); xv[0] = A_::ld(x + xi); if (relu == 1) zv[0] = A_::ld(z + zi); }
+  };
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * UF) {
+    long long xi[UF], zi[UF];
+    float dv[UF][VEC], xv[UF][VEC], zv[UF][VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float d = dv[e];
-      if (relu == 1 && !(zv[e] > 0.f)) d = 0.f;
-      if (relu == 2 && !(xv[e] * rsc + rsf > 0.f)) d = 0.f;
-      s0 += (double)d; s1 += (double)d * (double)((xv[e] - mu) * is);
+    for (int u = 0; u < UF; ++u) load_slot(min(i0 + 256 * u, total - 1), xi[u], zi[u], dv[u], xv[u], zv[u]);
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      if (i0 + 256 * u >= total) break;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float d = dv[u][e];
+        if (relu == 1 && !(zv[u][e] > 0.f)) d = 0.f;
+        if (relu == 2 && !(xv[u][e] * rsc + rsf > 0.f)) d = 0.f;
+        s0 += (double)d; s1 += (double)d * (double)((xv[u][e] - mu) * is);
+      }
     }
   }
   s0 = gca_block_sum256_d(s0, sh);
@@ -351,32 +384,36 @@ __global__ __launch_bounds__(256) void bn_bwd_small_kernel(
     if (dgamma) dgamma[c] += (float)s1;
   }
   const float A = (gamma ? gamma[c] : 1.f) * is, B = (float)(s0 / count), Cc = (float)(s1 / count);
-  for (int i = threadIdx.x; i < total; i += 256) {
-    const int n = i / per, sp = (i - n * per) * VEC;
-    const long long xi = ((long long)n * C + c) * SP + sp, zi = (long long)n * zs + (long long)c * SP + sp;
-    float dv[VEC], xv[VEC], zv[VEC], ov[VEC];
-    if (VEC == 4) {
-      const float4 d4 = A_::ld4(dzin + zi), x4 = A_::ld4(x + xi);
-      dv[0] = d4.x; dv[VEC > 1 ? 1 : 0] = d4.y; dv[VEC > 2 ? 2 : 0] = d4.z; dv[VEC > 3 ? 3 : 0] = d4.w;
-      xv[0] = x4.x; xv[VEC > 1 ? 1 : 0] = x4.y; xv[VEC > 2 ? 2 : 0] = x4.z; xv[VEC > 3 ? 3 : 0] = x4.w;
-      if (relu == 1) { const float4 z4 = A_::ld4(z + zi); zv[0] = z4.x; zv[VEC > 1 ? 1 : 0] = z4.y; zv[VEC > 2 ? 2 : 0] = z4.z; zv[VEC > 3 ? 3 : 0] = z4.w; }
-    } else { dv[0] = A_::ld(dzin + zi); xv[0] = A_::ld(x + xi); if (relu == 1) zv[0] = A_::ld(z + zi); }
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * UF) {
+    long long xi[UF], zi[UF];
+    float dv[UF][VEC], xv[UF][VEC], zv[UF][VEC];
+    float4 ro[UF];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      if (relu == 1 && !(zv[e] > 0.f)) dv[e] = 0.f;
-      if (relu == 2 && !(xv[e] * rsc + rsf > 0.f)) dv[e] = 0.f;
-      ov[e] = A * (dv[e] - B - (xv[e] - mu) * is * Cc);
+    for (int u = 0; u < UF; ++u) {
+      load_slot(min(i0 + 256 * u, total - 1), xi[u], zi[u], dv[u], xv[u], zv[u]);
+      if (dres && dres_acc) { if (VEC == 4) ro[u] = A_::ld4(dres + xi[u]); else ro[u].x = A_::ld(dres + xi[u]); }
     }
-    if (VEC == 4) {
-      A_::st4(dx + xi, make_float4(ov[0], ov[VEC > 1 ? 1 : 0], ov[VEC > 2 ? 2 : 0], ov[VEC > 3 ? 3 : 0]));
-      if (dres) {
-        float4 r = make_float4(dv[0], dv[VEC > 1 ? 1 : 0], dv[VEC > 2 ? 2 : 0], dv[VEC > 3 ? 3 : 0]);
-        if (dres_acc) { const float4 o = A_::ld4(dres + xi); r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w; }
-        A_::st4(dres + xi, r);
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      if (i0 + 256 * u >= total) break;
+      float ov[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        if (relu == 1 && !(zv[u][e] > 0.f)) dv[u][e] = 0.f;
+        if (relu == 2 && !(xv[u][e] * rsc + rsf > 0.f)) dv[u][e] = 0.f;
+        ov[e] = A * (dv[u][e] - B - (xv[u][e] - mu) * is * Cc);
       }
-    } else {
-      A_::st(dx + xi, ov[0]);
-      if (dres) A_::st(dres + xi, dres_acc ? A_::ld(dres + xi) + dv[0] : dv[0]);
+      if (VEC == 4) {
+        A_::st4(dx + xi[u], make_float4(ov[0], ov[VEC > 1 ? 1 : 0], ov[VEC > 2 ? 2 : 0], ov[VEC > 3 ? 3 : 0]));
+        if (dres) {
+          float4 r = make_float4(dv[u][0], dv[u][VEC > 1 ? 1 : 0], dv[u][VEC > 2 ? 2 : 0], dv[u][VEC > 3 ? 3 : 0]);
+          if (dres_acc) { r.x += ro[u].x; r.y += ro[u].y; r.z += ro[u].z; r.w += ro[u].w; }
+          A_::st4(dres + xi[u], r);
+        }
+      } else {
+        A_::st(dx + xi[u], ov[0]);
+        if (dres) A_::st(dres + xi[u], dres_acc ? ro[u].x + dv[u][0] : dv[u][0]);
+      }
     }
   }
 }
