@@ -466,7 +466,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   float s = 0.f;
   if (i < n) {
     int k = y;
-    for (; k + 12 < splits; k += 16) {              // four loads in flight per chain, summed in the fixed order
+    for (; k + 60 < splits; k += 64) {              // sixteen loads in flight per chain (the stem's wgrad has 200-500 slabs:
+      float l[16];                                  // four at a time was 30+ exposed round trips), summed in the fixed order
+#pragma unroll
+      for (int u = 0; u < 16; ++u) l[u] = slab[(long long)(k + 4 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += l[u];
+    }
+    for (; k + 12 < splits; k += 16) {              // four loads in flight per chain
       const float l0 = slab[(long long)k * n + i], l1 = slab[(long long)(k + 4) * n + i];
       const float l2 = slab[(long long)(k + 8) * n + i], l3 = slab[(long long)(k + 12) * n + i];
       s += l0; s += l1; s += l2; s += l3;
