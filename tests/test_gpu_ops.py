@@ -616,8 +616,9 @@ def test_gather_rows_contiguous_and_batch_strided_view(ops):
 
 @pytest.mark.parametrize('shape,k,s,p', [
     ((2, 5, 9, 14, 15), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # R(2+1)D / 3D-ResNet stem pool (W % 4 != 0: per-element backward)
-    ((2, 5, 9, 14, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # ... LDS-tiled backward, ragged boxes in D and H
-    ((1, 3, 8, 40, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # ... several boxes per plane in every dimension
+    ((2, 5, 9, 14, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # ... W % 4 == 0: paired-output forward, brick backward (odd D)
+    ((1, 3, 8, 40, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),     # ... many bricks per plane in every dimension
+    ((2, 3, 7, 9, 12), (3, 3, 3), (2, 2, 2), (1, 1, 1)),      # ... odd D and odd H: half-empty bricks at both ends
     ((2, 3, 4, 13, 11), (1, 3, 3), (1, 2, 2), (0, 1, 1)),     # S3D spatial pools
     ((2, 3, 5, 7, 9), (3, 3, 3), (1, 1, 1), (1, 1, 1)),       # S3D Mixed_* branch pool (cover 3x3x3)
     ((2, 3, 6, 8, 10), (2, 2, 2), (2, 2, 2), (0, 0, 0)),      # non-overlapping
@@ -642,6 +643,21 @@ def test_maxpool_random_vs_aten_with_ties(ops, shape, k, s, p):
     base = torch.randn(shape)
     dx2 = ops.maxpool_bwd(plan, dy.to(DEV), am, base.clone().to(DEV), True)
     assert rel_err(dx2, base + xr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('shape', [(1, 2, 5, 6, 8), (1, 2, 5, 6, 7)])
+def test_maxpool_nan_propagates_like_aten(ops, shape):
+    """ATen's rule is `val > max || isnan(val)`: a NaN in the window wins and later NaNs replace it.  Both stem-pool
+    kernels (paired outputs when W % 4 == 0, per output otherwise) must route values and indices the same way."""
+    torch.manual_seed(17)
+    x = torch.randn(shape)
+    x.view(-1)[torch.randperm(x.numel())[:x.numel() // 6]] = float('nan')
+    yr, ir = F.max_pool3d(x, 3, 2, 1, return_indices=True)
+    plan = ops.pool_plan(shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    y, am = ops.maxpool_fwd(plan, x.to(DEV))
+    assert torch.equal(torch.isnan(y.cpu()), torch.isnan(yr))
+    assert torch.equal(torch.nan_to_num(y.cpu(), nan=0.0), torch.nan_to_num(yr, nan=0.0))
+    assert torch.equal(am.cpu().long(), ir)
 
 
 def test_batched_weight_pack_equals_per_layer_pack(pkg, ops):

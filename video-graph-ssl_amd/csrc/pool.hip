@@ -34,8 +34,12 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
   const int d0 = od * g.sd - g.pd, h0 = oh * g.sh - g.ph, w0 = ow * g.sw - g.pw;
   const T* xp = x + (long long)plane * ((long long)g.D * g.H * g.W);
   float best = -INFINITY;
-  int bi = (max(d0, 0) * g.H + max(h0, 0)) * g.W + max(w0, 0);
+  const int safe = (max(d0, 0) * g.H + max(h0, 0)) * g.W + max(w0, 0);   // first in-bounds tap of the window
+  int bi = safe;
   if (KD > 0) {
+    // every tap's address is known up front (out-of-window taps read `safe`, never the running argmax: that would chain
+    // each load behind the previous compare), so the KD*KH*KW loads are issued together and the compares follow
+    float v[KD * KH * KW > 0 ? KD * KH * KW : 1];
 #pragma unroll
     for (int a = 0; a < KD; ++a)
 #pragma unroll
@@ -44,9 +48,18 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
         for (int c = 0; c < KW; ++c) {
           const int d = d0 + a, h = h0 + b, w = w0 + c;
           const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-          const int idx = (d * g.H + h) * g.W + w;
-          const float v = GCA_POOL_VAL((float)xp[ok ? idx : bi]);
-          if (ok && (v > best || isnan(v))) { best = v; bi = idx; }
+          v[(a * KH + b) * KW + c] = (float)xp[ok ? (d * g.H + h) * g.W + w : safe];
+        }
+#pragma unroll
+    for (int a = 0; a < KD; ++a)
+#pragma unroll
+      for (int b = 0; b < KH; ++b)
+#pragma unroll
+        for (int c = 0; c < KW; ++c) {
+          const int d = d0 + a, h = h0 + b, w = w0 + c;
+          const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+          const float t = GCA_POOL_VAL(v[(a * KH + b) * KW + c]);
+          if (ok && (t > best || isnan(t))) { best = t; bi = (d * g.H + h) * g.W + w; }
         }
   } else {
     const int d1 = min(d0 + g.kd, g.D), h1 = min(h0 + g.kh, g.H), w1 = min(w0 + g.kw, g.W);
@@ -61,6 +74,69 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(gca_pool_geom g, Poo
 #undef GCA_POOL_VAL
   y[i] = (T)best;
   if (argmax) argmax[i] = bi;
+}
+
+// 3x3x3 / stride 2 / pad 1 with W % 4 == 0 (every stem pool of the model zoo): one thread per PAIR of outputs adjacent in W.
+// The pair's windows span columns 4j-1 .. 4j+3, i.e. one aligned 4-element load per (d,h) row plus the left neighbour,
+// so a wave reads whole contiguous rows (18 loads per two outputs instead of 54 stride-2 ones), all issued before the
+// first compare.  Same tie break / NaN rule and the same fused BatchNorm+ReLU producer as maxpool3d_fwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3d_fwd_pair333s2_kernel(gca_pool_geom g, gca_magic psp, gca_magic phw,
+                                                                      gca_magic pw2, gca_magic cm, const T* __restrict__ x,
+                                                                      T* __restrict__ y, int* __restrict__ argmax,
+                                                                      unsigned npairs, const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift) {
+  typedef gca_act<T> A_;
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= npairs) return;
+  const unsigned plane = gca_fdiv(p, psp), o = p - plane * psp.d;
+  float sc = 1.f, sf = 0.f;
+  if (scale) { const unsigned c = plane - gca_fdiv(plane, cm) * cm.d; sc = scale[c]; sf = shift[c]; }
+#define GCA_POOL_VAL(v) (scale ? fmaxf((v) * sc + sf, 0.f) : (v))
+  const int od = (int)gca_fdiv(o, phw), r = (int)(o - (unsigned)od * phw.d);
+  const int oh = (int)gca_fdiv((unsigned)r, pw2), j = r - oh * (int)pw2.d;
+  const int d0 = 2 * od - 1, h0 = 2 * oh - 1, wq = 4 * j, wl = j > 0 ? wq - 1 : wq;
+  const T* xp = x + (long long)plane * ((long long)g.D * g.H * g.W);
+  const int safe_row = (max(d0, 0) * g.H + max(h0, 0)) * g.W;
+  float4 m[9];
+  float l[9];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int d = d0 + a, h = h0 + b;
+      const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H;
+      const int row = ok ? (d * g.H + h) * g.W : safe_row;
+      m[a * 3 + b] = A_::ld4(xp + row + wq);
+      l[a * 3 + b] = A_::ld(xp + row + wl);
+    }
+  float b0 = -INFINITY, b1 = -INFINITY;
+  int i0 = safe_row + wl, i1 = safe_row + wq + 1;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int d = d0 + a, h = h0 + b;
+      const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H;
+      const int row = (d * g.H + h) * g.W + wq;
+      const float vl = GCA_POOL_VAL(l[a * 3 + b]), v0 = GCA_POOL_VAL(m[a * 3 + b].x), v1 = GCA_POOL_VAL(m[a * 3 + b].y),
+                  v2 = GCA_POOL_VAL(m[a * 3 + b].z), v3 = GCA_POOL_VAL(m[a * 3 + b].w);
+      if (ok && j > 0 && (vl > b0 || isnan(vl))) { b0 = vl; i0 = row - 1; }
+      if (ok && (v0 > b0 || isnan(v0))) { b0 = v0; i0 = row; }
+      if (ok && (v1 > b0 || isnan(v1))) { b0 = v1; i0 = row + 1; }
+      if (ok && (v1 > b1 || isnan(v1))) { b1 = v1; i1 = row + 1; }
+      if (ok && (v2 > b1 || isnan(v2))) { b1 = v2; i1 = row + 2; }
+      if (ok && (v3 > b1 || isnan(v3))) { b1 = v3; i1 = row + 3; }
+    }
+#undef GCA_POOL_VAL
+  if (sizeof(T) == 4) {
+    *reinterpret_cast<float2*>(y + 2ull * p) = make_float2(b0, b1);
+  } else {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    h2 ov; ov.x = (_Float16)b0; ov.y = (_Float16)b1;
+    *reinterpret_cast<h2*>(y + 2ull * p) = ov;
+  }
+  if (argmax) *reinterpret_cast<int2*>(argmax + 2ull * p) = make_int2(i0, i1);
 }
 
 // One thread per INPUT element: gathers from the (few) windows that cover it, no atomics (deterministic, fixed
@@ -114,71 +190,79 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(gca_pool_geom g, Poo
   dx[i] = (T)(accumulate ? (float)dx[i] + acc : acc);
 }
 
-// LDS-tiled backward of the 3x3x3 / stride 2 / pad 1 pools behind the R(2+1)D and 3D-ResNet stems (resnet2p1d.py:178,
-// resnet.py:127): a block owns a box of 4 x 16 x 16 INPUT elements of one plane; the <= 3 x 9 x 9
-// windows that can cover them are staged once as (argmax, dy) pairs -- half a load per input element instead of sixteen --
-// and every thread finishes four consecutive-w elements (one 16-byte store), summing the matching windows in the same
-// (od, oh, ow) order as maxpool3d_bwd_kernel (deterministic, no atomics): 0.32 vs 0.48 ms on the (32,64,16,56,56) stem map.
-// (The same tiling of the FORWARD pool -- 5 x 17 x 33 inputs staged per 2 x 8 x 16 outputs, producer evaluated once per
-// staged input -- was measured and not kept: 0.35 vs 0.32 ms.)
-constexpr int PB_D = 4, PB_H = 16, PB_W = 16;
-constexpr int PB_OD = PB_D / 2 + 1, PB_OH = PB_H / 2 + 1, PB_OW = PB_W / 2 + 1;
+// Backward of the 3x3x3 / stride 2 / pad 1 pools behind the R(2+1)D and 3D-ResNet stems (resnet2p1d.py:178, resnet.py:127)
+// with W % 4 == 0.  Window o covers inputs 2o-1 .. 2o+1, so the 2 x 2 x 4 input brick d in {2n, 2n+1}, h in {2m, 2m+1},
+// w in 4j .. 4j+3 can only be the argmax of windows od in {n, n+1} x oh in {m, m+1} x ow in {2j, 2j+1, 2j+2}: one thread
+// fetches those twelve (argmax, dy) pairs (an aligned pair + one scalar per (od,oh), all issued before the first compare;
+// invalid slots read a clamped, valid address and are masked) and finishes the brick's sixteen elements with four 16-byte
+// stores.  Summation order (od, oh, ow) ascending as in maxpool3d_bwd_kernel: deterministic, no atomics; 32-bit index
+// arithmetic (the host checks total < 2^31).  Earlier forms on the (32,64,16,56,56) stem map: per element 0.48 ms, an
+// LDS-staged 4x16x16 box 0.32 ms, one thread per 4 elements with the same twelve loads 0.30 ms (one exposed round trip per
+// wave: 400 K short waves).  The same LDS tiling of the FORWARD pool was measured at 0.35 ms and dropped for the
+// paired-output kernel above.
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool3d_bwd_tiled333s2_kernel(gca_pool_geom g, const T* __restrict__ dy,
-                                                                     const int* __restrict__ argmax, T* __restrict__ dx,
-                                                                     int accumulate, int nbd, int nbh, int nbw) {
-  __shared__ int am_s[PB_OD][PB_OH][PB_OW];
-  __shared__ float dy_s[PB_OD][PB_OH][PB_OW];
-  const int tid = threadIdx.x;
-  int b = blockIdx.x;
-  const int tbw = b % nbw; b /= nbw;
-  const int tbh = b % nbh; b /= nbh;
-  const int tbd = b % nbd;
-  const int plane = b / nbd;
-  const int d0 = tbd * PB_D, h0 = tbh * PB_H, w0 = tbw * PB_W;
-  const int od0 = d0 / 2, oh0 = h0 / 2, ow0 = w0 / 2;             // first window that can cover the box (window o covers 2o-1 .. 2o+1)
-  const long long obase = (long long)plane * ((long long)g.OD * g.OH * g.OW);
-  if (tid < PB_OD * PB_OH * PB_OW) {
-    const int zd = tid / (PB_OH * PB_OW), r = tid - zd * (PB_OH * PB_OW), zh = r / PB_OW, zw = r - zh * PB_OW;
-    const int od = od0 + zd, oh = oh0 + zh, ow = ow0 + zw;
-    int a = -1;
-    float v = 0.f;
-    if (od < g.OD && oh < g.OH && ow < g.OW) {
-      const long long o = obase + ((long long)od * g.OH + oh) * g.OW + ow;
-      a = argmax[o];
-      v = (float)dy[o];
-    }
-    am_s[zd][zh][zw] = a;
-    dy_s[zd][zh][zw] = v;
-  }
-  __syncthreads();
-  const int w4 = (tid & 3) * 4, lh = (tid >> 2) & 15, ld = tid >> 6;
-  const int d = d0 + ld, h = h0 + lh, w = w0 + w4;
-  if (d >= g.D || h >= g.H || w >= g.W) return;                  // (W % 4 == 0: a group of four is all inside or all outside)
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  // window o covers i  <=>  2o - 1 <= i <= 2o + 1:  i even -> o = i/2 only, i odd -> o in {(i-1)/2, (i+1)/2}
-  const int od_first = (d + 1) / 2 - (d & 1), od_last = (d + 1) / 2;
-  const int oh_first = (h + 1) / 2 - (h & 1), oh_last = (h + 1) / 2;
+__global__ __launch_bounds__(256) void maxpool3d_bwd_brick333s2_kernel(gca_pool_geom g, gca_magic msp, gca_magic mhw, gca_magic mw,
+                                                                       const T* __restrict__ dy, const int* __restrict__ argmax,
+                                                                       T* __restrict__ dx, unsigned nbricks, int accumulate) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nbricks) return;
+  const unsigned plane = gca_fdiv(t, msp), sidx = t - plane * msp.d;
+  const int n = (int)gca_fdiv(sidx, mhw), r = (int)(sidx - (unsigned)n * mhw.d);
+  const int m = (int)gca_fdiv((unsigned)r, mw), j = r - m * (int)mw.d;
+  const bool vd1 = n + 1 < g.OD, vh1 = m + 1 < g.OH, vw2 = 2 * j + 2 < g.OW;           // (n < OD = ceil(D/2), m < OH always)
+  const unsigned o00 = ((plane * (unsigned)g.OD + (unsigned)n) * (unsigned)g.OH + (unsigned)m) * (unsigned)g.OW + 2u * (unsigned)j;
+  const unsigned step_d = vd1 ? (unsigned)(g.OH * g.OW) : 0u, step_h = vh1 ? (unsigned)g.OW : 0u, step_w = vw2 ? 2u : 1u;
+  int2 a01[4];
+  int a2[4];
+  float g0[4], g1[4], g2[4];
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const int wi = w + e;
-    const int s_idx = (d * g.H + h) * g.W + wi;
-    const int ow_first = (wi + 1) / 2 - (wi & 1), ow_last = (wi + 1) / 2;
-    float a = 0.f;
-    for (int od = od_first; od <= od_last; ++od)
-      for (int oh = oh_first; oh <= oh_last; ++oh)
-        for (int ow = ow_first; ow <= ow_last; ++ow) {
-          if (od >= g.OD || oh >= g.OH || ow >= g.OW) continue;
-          if (am_s[od - od0][oh - oh0][ow - ow0] == s_idx) a += dy_s[od - od0][oh - oh0][ow - ow0];
+  for (int c = 0; c < 4; ++c) {                                   // c = 2*(od - n) + (oh - m)
+    const unsigned o = o00 + ((c & 2) ? step_d : 0u) + ((c & 1) ? step_h : 0u);
+    a01[c] = *reinterpret_cast<const int2*>(argmax + o);
+    a2[c] = argmax[o + step_w];
+    if (sizeof(T) == 4) {
+      const float2 v = *reinterpret_cast<const float2*>(dy + o);
+      g0[c] = v.x; g1[c] = v.y;
+    } else {
+      typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+      const h2 v = *reinterpret_cast<const h2*>(dy + o);
+      g0[c] = (float)v.x; g1[c] = (float)v.y;
+    }
+    g2[c] = (float)dy[o + step_w];
+  }
+  // masked slots can match nothing
+  if (!vw2) { a2[0] = a2[1] = a2[2] = a2[3] = -1; }
+  if (!vd1) { a01[2] = a01[3] = make_int2(-1, -1); a2[2] = a2[3] = -1; }
+  if (!vh1) { a01[1] = a01[3] = make_int2(-1, -1); a2[1] = a2[3] = -1; }
+  const unsigned plane_base = plane * (unsigned)(g.D * g.H * g.W);
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int d = 2 * n + dd, h = 2 * m + hh;
+      if (d >= g.D || h >= g.H) continue;
+      const int s0 = (d * g.H + h) * g.W + 4 * j;                 // plane-relative index of the quad's first element
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int cd = 0; cd <= dd; ++cd)                            // even d / h lie in one window only, odd ones in two
+#pragma unroll
+        for (int ch = 0; ch <= hh; ++ch) {
+          const int c = 2 * cd + ch;
+          // window 2j covers w 4j-1..4j+1, window 2j+1 covers 4j+1..4j+3, window 2j+2 covers 4j+3..4j+5
+          acc[0] += a01[c].x == s0 ? g0[c] : 0.f;
+          acc[1] += a01[c].x == s0 + 1 ? g0[c] : 0.f;
+          acc[1] += a01[c].y == s0 + 1 ? g1[c] : 0.f;
+          acc[2] += a01[c].y == s0 + 2 ? g1[c] : 0.f;
+          acc[3] += a01[c].y == s0 + 3 ? g1[c] : 0.f;
+          acc[3] += a2[c] == s0 + 3 ? g2[c] : 0.f;
         }
-    acc[e] = a;
-  }
-  T* out = dx + (long long)plane * ((long long)g.D * g.H * g.W) + (long long)(d * g.H + h) * g.W + w;
-  if (accumulate) {
-    const float4 o = gca_act<T>::ld4(out);
-    acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
-  }
-  gca_act<T>::st4(out, make_float4(acc[0], acc[1], acc[2], acc[3]));
+      T* out = dx + (plane_base + (unsigned)s0);
+      if (accumulate) {
+        const float4 o = gca_act<T>::ld4(out);
+        acc[0] += o.x; acc[1] += o.y; acc[2] += o.z; acc[3] += o.w;
+      }
+      gca_act<T>::st4(out, make_float4(acc[0], acc[1], acc[2], acc[3]));
+    }
 }
 
 // y[p] = norm * sum_d wt[d] * sum_hw x[p,d,hw]; one wave per (n,c) plane.
@@ -261,6 +345,23 @@ int gca_maxpool3d_fwd(const gca_pool_geom* g, const void* x, void* y, int32_t* a
       hipLaunchKernelGGL((maxpool3d_fwd_kernel<float, KD, KH, KW>), grid, dim3(256), 0, st, *g, q, (const float*)x,         \
                          (float*)y, argmax, (unsigned)total, scale, shift);                                                 \
   } while (0)
+  const size_t esz = act_f16 ? 2 : 4;
+  if (g->kd == 3 && g->kh == 3 && g->kw == 3 && g->sd == 2 && g->sh == 2 && g->sw == 2 && g->pd == 1 && g->ph == 1 && g->pw == 1 &&
+      g->W % 4 == 0 && ((uintptr_t)x % (4 * esz)) == 0 && ((uintptr_t)y % (2 * esz)) == 0 && ((uintptr_t)argmax % 8) == 0 &&
+      pool_tiled_on()) {
+    // OW = W/2 is even here, so output pairs never straddle a row and pair p covers outputs 2p, 2p+1
+    const unsigned npairs = (unsigned)(total / 2);
+    const gca_magic psp = gca_make_magic((unsigned)(g->OD * g->OH * (g->OW / 2))), phw = gca_make_magic((unsigned)(g->OH * (g->OW / 2))),
+                    pw2 = gca_make_magic((unsigned)(g->OW / 2));
+    const dim3 pgrid((unsigned)gca_ceil_div((long long)npairs, 256));
+    if (act_f16)
+      hipLaunchKernelGGL(maxpool3d_fwd_pair333s2_kernel<gca_half>, pgrid, dim3(256), 0, st, *g, psp, phw, pw2, q.c, (const gca_half*)x,
+                         (gca_half*)y, argmax, npairs, scale, shift);
+    else
+      hipLaunchKernelGGL(maxpool3d_fwd_pair333s2_kernel<float>, pgrid, dim3(256), 0, st, *g, psp, phw, pw2, q.c, (const float*)x,
+                         (float*)y, argmax, npairs, scale, shift);
+    return gca_launch_status();
+  }
   if (g->kd == 3 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(3, 3, 3);
   else if (g->kd == 1 && g->kh == 3 && g->kw == 3) GCA_POOL_FWD(1, 3, 3);
   else if (g->kd == 2 && g->kh == 2 && g->kw == 2) GCA_POOL_FWD(2, 2, 2);
@@ -288,18 +389,21 @@ int gca_maxpool3d_bwd(const gca_pool_geom* g, const void* dy, const int32_t* arg
                          argmax, (float*)dx, (unsigned)total, accumulate ? 1 : 0);                                         \
   } while (0)
   if (g->kd == 3 && g->kh == 3 && g->kw == 3 && g->sd == 2 && g->sh == 2 && g->sw == 2 && g->pd == 1 && g->ph == 1 && g->pw == 1 &&
-      g->W % 4 == 0 && ((long long)g->D * g->H * g->W) % 4 == 0 && ((uintptr_t)dx % 16) == 0 && pool_tiled_on()) {
-    const int nbd = (int)gca_ceil_div(g->D, PB_D), nbh = (int)gca_ceil_div(g->H, PB_H), nbw = (int)gca_ceil_div(g->W, PB_W);
-    const long long nblk = (long long)g->N * g->C * nbd * nbh * nbw;
-    if (nblk <= 0x7fffffffLL) {
-      if (act_f16)
-        hipLaunchKernelGGL(maxpool3d_bwd_tiled333s2_kernel<gca_half>, dim3((unsigned)nblk), dim3(256), 0, st, *g, (const gca_half*)dy,
-                           argmax, (gca_half*)dx, accumulate ? 1 : 0, nbd, nbh, nbw);
-      else
-        hipLaunchKernelGGL(maxpool3d_bwd_tiled333s2_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, st, *g, (const float*)dy,
-                           argmax, (float*)dx, accumulate ? 1 : 0, nbd, nbh, nbw);
-      return gca_launch_status();
-    }
+      g->W % 4 == 0 && ((uintptr_t)dx % (act_f16 ? 8 : 16)) == 0 && ((uintptr_t)dy % (act_f16 ? 4 : 8)) == 0 &&
+      ((uintptr_t)argmax % 8) == 0 && pool_tiled_on()) {
+    // OW = W/2 is even: the (argmax, dy) pair of windows 2j, 2j+1 is aligned
+    const int d2 = (g->D + 1) / 2, h2 = (g->H + 1) / 2, w4 = g->W / 4;
+    const unsigned nbricks = (unsigned)((long long)g->N * g->C * d2 * h2 * w4);
+    const gca_magic msp = gca_make_magic((unsigned)(d2 * h2 * w4)), mhw = gca_make_magic((unsigned)(h2 * w4)),
+                    mw = gca_make_magic((unsigned)w4);
+    const dim3 bgrid((unsigned)gca_ceil_div((long long)nbricks, 256));
+    if (act_f16)
+      hipLaunchKernelGGL(maxpool3d_bwd_brick333s2_kernel<gca_half>, bgrid, dim3(256), 0, st, *g, msp, mhw, mw, (const gca_half*)dy,
+                         argmax, (gca_half*)dx, nbricks, accumulate ? 1 : 0);
+    else
+      hipLaunchKernelGGL(maxpool3d_bwd_brick333s2_kernel<float>, bgrid, dim3(256), 0, st, *g, msp, mhw, mw, (const float*)dy,
+                         argmax, (float*)dx, nbricks, accumulate ? 1 : 0);
+    return gca_launch_status();
   }
   if (cd == 2 && ch == 2 && cw == 2) GCA_POOL_BWD(2, 2, 2);
   else if (cd == 1 && ch == 2 && cw == 2) GCA_POOL_BWD(1, 2, 2);
