@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pmc_step
 mkdir -p $O
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-other-math ${GCA_BENCH_MATH:+--math $GCA_BENCH_MATH}"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-other-math ${GCA_BENCH_MATH:+--math $GCA_BENCH_MATH} $GCA_BENCH_ARGS"
 export GCA_TUNE_CACHE=$O/tune_cache.json      # pass 1 measures the launch configurations, passes 2-3 reuse them
 rm -f $GCA_TUNE_CACHE
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py $ARGS > $O/trace.json 2> $O/trace.err || exit 1
