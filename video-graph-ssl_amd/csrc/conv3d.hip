@@ -713,7 +713,8 @@ __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
 
 // Split-K finishing pass, grid (channels, parts): sum the slabs in fixed order, add bias, (+=) store in
 // NCDHW (through the class's destination map), and emit the BN partial sums [K][parts].
-constexpr int FINISH_CHUNK = 1024;      // columns per finishing block: split-K grids are small, so many short blocks (4 columns per thread)
+constexpr int FINISH_CHUNK = 1024;      // columns per finishing block: split-K grids are small, so many short blocks (4 columns per thread;
+                                        // issuing the slab loads of all four columns together was measured: 9.1 vs 8.6 us per launch, not kept)
 template <typename T>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(
     const float* __restrict__ slab, int splits, const float* __restrict__ bias, T* __restrict__ dst,

@@ -489,6 +489,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// The same reduction for n % 4 == 0 (every layer with an output-channel count that is a multiple of four): a thread owns
+// FOUR consecutive outputs and reads the slabs with 16-byte loads; per output the summation order is exactly that of
+// splitk_reduce_kernel (slabs y, y+4, ... per wave, then the four partial sums), so both give the same bits.
+__global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float4* __restrict__ slab, float4* __restrict__ dw,
+                                                             long long n4, int splits, int accumulate) {
+  __shared__ float4 sh[4][64];
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + x;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (i < n4) {
+    int k = y;
+    for (; k + 60 < splits; k += 64) {
+      float4 l[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) l[u] = slab[(long long)(k + 4 * u) * n4 + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { s.x += l[u].x; s.y += l[u].y; s.z += l[u].z; s.w += l[u].w; }
+    }
+    for (; k + 12 < splits; k += 16) {
+      const float4 l0 = slab[(long long)k * n4 + i], l1 = slab[(long long)(k + 4) * n4 + i];
+      const float4 l2 = slab[(long long)(k + 8) * n4 + i], l3 = slab[(long long)(k + 12) * n4 + i];
+      s.x += l0.x; s.y += l0.y; s.z += l0.z; s.w += l0.w;
+      s.x += l1.x; s.y += l1.y; s.z += l1.z; s.w += l1.w;
+      s.x += l2.x; s.y += l2.y; s.z += l2.z; s.w += l2.w;
+      s.x += l3.x; s.y += l3.y; s.z += l3.z; s.w += l3.w;
+    }
+    for (; k < splits; k += 4) {
+      const float4 l = slab[(long long)k * n4 + i];
+      s.x += l.x; s.y += l.y; s.z += l.z; s.w += l.w;
+    }
+  }
+  sh[y][x] = s;
+  __syncthreads();
+  if (y == 0 && i < n4) {
+    const float4 a = sh[0][x], b = sh[1][x], c = sh[2][x], d = sh[3][x];
+    float4 t = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    if (accumulate) { const float4 o = dw[i]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    dw[i] = t;
+  }
+}
+
 __global__ void bias_grad_kernel(const float* __restrict__ dy, long long N, long long K, long long SP,
                                  float* __restrict__ db, int accumulate) {
   __shared__ float sh[4];
@@ -666,8 +707,12 @@ int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, cons
   rc = gca_launch_status();
   if (rc) return rc;
   const long long n = (long long)g->K * p.Kred;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 64)), dim3(256), 0, st, slab, dw, n,
-                     p.splits, accumulate ? 1 : 0);
+  if (n % 4 == 0 && ((uintptr_t)slab % 16) == 0 && ((uintptr_t)dw % 16) == 0)
+    hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)gca_ceil_div(n / 4, 64)), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(dw), n / 4, p.splits, accumulate ? 1 : 0);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 64)), dim3(256), 0, st, slab, dw, n,
+                       p.splits, accumulate ? 1 : 0);
   return gca_launch_status();
 }
 
