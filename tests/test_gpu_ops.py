@@ -660,6 +660,33 @@ def test_maxpool_nan_propagates_like_aten(ops, shape):
     assert torch.equal(am.cpu().long(), ir)
 
 
+def test_wgrad_splitk_reduce_vector_and_scalar_forms_give_the_same_bits(ops):
+    """The split-K reduce reads the slabs with 16-byte loads when the weight count and the gradient pointer allow it and
+    per element otherwise; per output the summation order is the same, so a gradient written at a 16-byte aligned address
+    and one written four bytes further must be identical (and accumulate=True must add to what is there)."""
+    torch.manual_seed(23)
+    shape, K, k, s, p = (4, 24, 6, 14, 14), 40, (3, 1, 1), (1, 1, 1), (1, 0, 0)
+    x, dy_shape = torch.randn(shape, device=DEV), None
+    plan = ops.conv_plan(shape, K, k, s, p, DEV)
+    dy = torch.randn(plan.out_shape, device=DEV)
+    n = K * shape[1] * 3
+    buf = torch.zeros(n + 8, device=DEV)
+    assert buf.data_ptr() % 16 == 0 and n % 4 == 0
+    a = buf[0:n].view(K, shape[1], 3, 1, 1)
+    ops.conv_wgrad(plan, x, dy, a, False)
+    a = a.clone()
+    b = buf[1:n + 1].view(K, shape[1], 3, 1, 1)                   # 4 bytes off: the per-element kernel
+    ops.conv_wgrad(plan, x, dy, b, False)
+    assert torch.equal(a, b)
+    base = torch.randn(n + 8, device=DEV)
+    c0, c1 = base.clone(), base.clone()
+    ops.conv_wgrad(plan, x, dy, c0[0:n].view(K, shape[1], 3, 1, 1), True)
+    ops.conv_wgrad(plan, x, dy, c1[1:n + 1].view(K, shape[1], 3, 1, 1), True)
+    assert rel_err(c0[0:n], base[0:n] + a.flatten()) < 1e-6 and rel_err(c1[1:n + 1], base[1:n + 1] + a.flatten()) < 1e-6
+    ref = torch.nn.grad.conv3d_weight(x.cpu().double(), (K, shape[1]) + k, dy.cpu().double(), s, p).float()
+    assert rel_err(a, ref) < 1e-3
+
+
 def test_batched_weight_pack_equals_per_layer_pack(pkg, ops):
     """gca_conv_pack_batched (one launch per encoder) must write exactly what gca_conv_pack writes per layer."""
     L = pkg.engine.layers
