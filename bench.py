@@ -38,6 +38,28 @@ def log(msg):
     sys.stderr.flush()
 
 
+# stdout carries exactly ONE line, the JSON result of rank 0.  Native libraries write to file descriptor 1 behind
+# Python's back (RCCL prints a five-line version banner there when the first communicator is created), so descriptor 1 is
+# pointed at stderr for the life of the process and the result goes to a private duplicate of the original stdout.
+_RESULT_FD = [None]
+
+
+def claim_stdout():
+    if _RESULT_FD[0] is None:
+        sys.stdout.flush()
+        _RESULT_FD[0] = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(res):
+    line = (json.dumps(res) + '\n').encode()
+    if _RESULT_FD[0] is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD[0], line)
+
+
 T_START = time.time()
 
 
@@ -383,7 +405,7 @@ def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
                             peak=PEAK_HBM_GBPS, unit='GB/s', frac=gt['hbm_frac'], traffic=pmc_hbm('tmix_kernel<8>') if (bsz, size) == (4, 224) else None, avg_launch_ms=gt['ms'],
                             algorithmic_MB=gt['algorithmic_MB']),
            'graph_mix_fwd': gt}
-    print(json.dumps(res))
+    emit(res)
 
 
 def host_cores():
@@ -443,6 +465,7 @@ def cpu_baseline(args, K):
 
 def main():
     args = parse()
+    claim_stdout()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -478,6 +501,16 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world,      # "nccl" == RCCL on ROCm
                                     device_id=dev)
         ctx = pkg.parallel.DistCtx(rank, world, None, host_staged=rehearsal)
+    # GCA_BENCH_DIST_SHAPE=1 at N = 1: run the step in its N > 1 SHAPE (graph segments, ShuffleBN exchange, key gather,
+    # bucketed all-reduce overlapped with backward -- real RCCL calls in a one-rank group) on one GPU: what the multi-GPU
+    # control flow costs before any byte crosses xGMI.  The JSON line says so; it is not the N = 1 measurement.
+    dist_shape = world == 1 and os.environ.get('GCA_BENCH_DIST_SHAPE', '0') == '1'
+    if dist_shape:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29517')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+        ctx = pkg.parallel.DistCtx(0, 1, None, force_active=True)
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
@@ -519,6 +552,9 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    elif dist_shape:
+        import torch.distributed as dist
+        dist.destroy_process_group()
     if rank != 0:
         return
     log('timed region %.3fs, loss %.4f' % (dt, loss))
@@ -533,7 +569,8 @@ def main():
         'config': {'workload': 'MoCo pre-training iteration, %s, %d-frame %dx%d clips, %d clips/GPU (global %d), '
                                'queue K=%d, T=0.07, SGD+EMA (BASELINE.json configs[%d])'
                                % (args.backbone, args.frames, args.size, args.size, args.batch, global_batch, K, cfg_idx),
-                   'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, **({'rehearsal': 'gloo/host-staged on one GPU: NOT a measurement'} if rehearsal else {})},
+                   'global_batch': global_batch, 'parallelism': 'dp%d' % world, 'hipgraph': not args.no_graph, **({'rehearsal': 'gloo/host-staged on one GPU: NOT a measurement'} if rehearsal else {}),
+                   **({'dist_shape': 'N > 1 step shape (segments + RCCL calls) in a one-rank group: control-flow cost only'} if dist_shape else {})},
         'views_per_sec': round(2 * value, 3), 'final_loss': round(loss, 5),
     }
     if step_gflop:
@@ -578,7 +615,7 @@ def main():
     if world == 1:
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, K)
-    print(json.dumps(res))
+    emit(res)
 
 
 if __name__ == '__main__':

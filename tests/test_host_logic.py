@@ -301,3 +301,25 @@ def test_exchange_plan_bookkeeping(pkg):
         assert sum(send_counts) == b == sum(recv_counts) and sorted(place.tolist()) == list(range(b))
         for d in range(world):
             assert send_counts[d] == sends[d][2][r]          # what r sends to d is what d expects from r
+
+
+def test_bench_stdout_carries_only_the_result_line():
+    """bench.py's contract is ONE JSON line on stdout.  RCCL writes a version banner to file descriptor 1 from native code when
+    the first communicator is created (seen on the GPU box), so bench.py points descriptor 1 at stderr and emits the result
+    through a private duplicate of the original stdout: native writes and stray prints must land on stderr."""
+    import subprocess
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent('''
+        import os, sys
+        sys.path.insert(0, %r)
+        import bench
+        bench.claim_stdout()
+        os.write(1, b"native banner\\n")
+        print("python print")
+        bench.emit({"metric": "m", "value": 1})
+    ''' % root)
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    assert r.stdout == '{"metric": "m", "value": 1}\n'
+    assert 'native banner' in r.stderr and 'python print' in r.stderr
