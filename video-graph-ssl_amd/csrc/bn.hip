@@ -116,7 +116,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
   const int c = blockIdx.x;
   if (nbt && c == 0 && threadIdx.x == 0) *nbt += 1;          // num_batches_tracked (BatchNorm bookkeeping)
   double s = 0.0, q = 0.0;
-  for (long long i = threadIdx.x; i < P; i += 256) { s += (double)psum[c * P + i]; q += (double)psq[c * P + i]; }
+  {
+    // eight partials of each array in flight per thread (P reaches several thousand on the big layers: one dependent load per
+    // trip was 20+ exposed round trips); the accumulation order per thread is unchanged
+    const float* ps = psum + c * P;
+    const float* pq = psq + c * P;
+    long long i = threadIdx.x;
+    for (; i + 7 * 256 < P; i += 8 * 256) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = ps[i + u * 256]; b[u] = pq[i + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += (double)a[u]; q += (double)b[u]; }
+    }
+    for (; i < P; i += 256) { s += (double)ps[i]; q += (double)pq[i]; }
+  }
   s = gca_block_sum256_d(s, sh);
   q = gca_block_sum256_d(q, sh);
   if (threadIdx.x == 0) {
@@ -187,7 +201,19 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
   __shared__ double sh[4];
   const int c = blockIdx.x;
   double s0 = 0.0, s1 = 0.0;
-  for (int i = threadIdx.x; i < P; i += 256) { s0 += (double)p0[(long long)c * P + i]; s1 += (double)p1[(long long)c * P + i]; }
+  {
+    const float* q0 = p0 + (long long)c * P;
+    const float* q1 = p1 + (long long)c * P;
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < P; i += 8 * 256) {          // eight partials of each array in flight (see bn_finalize_kernel)
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = q0[i + u * 256]; b[u] = q1[i + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
+    }
+    for (; i < P; i += 256) { s0 += (double)q0[i]; s1 += (double)q1[i]; }
+  }
   s0 = gca_block_sum256_d(s0, sh);
   s1 = gca_block_sum256_d(s1, sh);
   if (threadIdx.x == 0) {
@@ -266,7 +292,21 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
   const int c = blockIdx.x;
   if (nbt && c == 0 && threadIdx.x == 0) *nbt += 1;
   double s = 0.0, q = 0.0;
-  for (long long i = threadIdx.x; i < P; i += 256) { s += (double)psum[c * P + i]; q += (double)psq[c * P + i]; }
+  {
+    // eight partials of each array in flight per thread (P reaches several thousand on the big layers: one dependent load per
+    // trip was 20+ exposed round trips); the accumulation order per thread is unchanged
+    const float* ps = psum + c * P;
+    const float* pq = psq + c * P;
+    long long i = threadIdx.x;
+    for (; i + 7 * 256 < P; i += 8 * 256) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a[u] = ps[i + u * 256]; b[u] = pq[i + u * 256]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += (double)a[u]; q += (double)b[u]; }
+    }
+    for (; i < P; i += 256) { s += (double)ps[i]; q += (double)pq[i]; }
+  }
   s = gca_block_sum256_d(s, sh);
   q = gca_block_sum256_d(q, sh);
   if (threadIdx.x == 0) {
