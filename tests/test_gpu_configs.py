@@ -150,8 +150,9 @@ def test_configs3_assembled_s3d_graph_simsiam(pkg, math):
     """MODEL.AUG_FLAG = True: S3D with the temporal-graph block inserted before Mixed_3b / Mixed_4c / Mixed_5b
     (8 / 4 / 2 graph nodes for 16-frame clips) + SimSiam projection / prediction MLPs, loss and gradients through the
     reference-shaped API (model(images) -> loss; loss.backward()), RelaxedBernoulli noise injected at the three sites.
-    Truth = the oracle in fp64; the fp32 CPU oracle's own distance from it is the yardstick for the gradients (S3D's 77
-    BatchNorms + 13 max pools make fp32 gradients chaotic for ANY implementation: tools/diag_s3d_bwd.py)."""
+    Truth = the oracle in fp64; the fp32 CPU oracle's own distance from it -- the largest of three runs, two of them on inputs
+    moved by one fp32 rounding -- is the yardstick for the gradients (S3D's 77 BatchNorms + 13 max pools make fp32 gradients
+    chaotic for ANY implementation: tools/diag_s3d_bwd.py)."""
     from oracle import wrappers as owrap
     default = pkg.engine.ops.get_conv_math()
     pkg.engine.ops.set_conv_math(math)
@@ -165,17 +166,21 @@ def test_configs3_assembled_s3d_graph_simsiam(pkg, math):
         x = torch.randn(4, 6, 16, 112, 112, generator=gen)       # configs[3]'s clip length, 112x112 crops
         noise = [torch.rand(4, t, t, generator=gen) for t in (8, 4, 2)]
 
-        def reference(double):
+        def reference(double, xin=None):
             ref, _ = owrap.create_visual_model('S3D', 16, 1024, 'mlp', 'simsiam', aug_flag=True)
             ref.load_state_dict(sd)
             ref = (ref.double() if double else ref).train()
             for (_, site), u in zip(_aug_sites(model.model.encoder.base_model, ref.model.encoder.base_model), noise):
                 site.noise = u.double() if double else u
-            loss = ref(x.double() if double else x)
+            xin = x if xin is None else xin
+            loss = ref(xin.double() if double else xin)
             loss.backward()
             return ref, loss.detach()
         r64, l64 = reference(True)
         r32, l32 = reference(False)
+        # the yardstick is a DISTRIBUTION, not one draw: two more fp32 CPU runs on inputs moved by one fp32 rounding
+        # (x * (1 +- 2^-23)) show how far a correct fp32 implementation with different roundings lands from the fp64 truth
+        r32_alt = [reference(False, x * (1.0 + sgn * 2.0 ** -23))[0] for sgn in (1.0, -1.0)]
         model.to(DEV).train()
         for (aug, _), u in zip(_aug_sites(model.model.encoder.base_model, r64.model.encoder.base_model), noise):
             assert type(aug).__name__ == 'TemporalGraphAug'
@@ -195,7 +200,11 @@ def test_configs3_assembled_s3d_graph_simsiam(pkg, math):
         e32 = {n: parity.rel(g32[n], g64[n]) for n in errs}
         assert len(errs) > 200
         med = lambda d: sorted(d.values())[len(d) // 2]
-        assert med(errs) < 3 * med(e32) + 1e-4, (med(errs), med(e32))
+        e32_alt = [{n: parity.rel(dict(r.named_parameters())[n].grad, g64[n]) for n in errs} for r in r32_alt]
+        yard = max([med(e32)] + [med(e) for e in e32_alt])
+        print('configs[3] %s: gradient median error %.3e; fp32 CPU oracle %.3e, perturbed %s'
+              % (math, med(errs), med(e32), ['%.3e' % med(e) for e in e32_alt]))
+        assert med(errs) < 3 * yard + 1e-4, (med(errs), med(e32), [med(e) for e in e32_alt])
         # the graph blocks' own parameters (8-, 4- and 2-node sites), the stem and the predictor head
         pre = 'model.encoder.base_model.'
         for n in (pre + 'base.5.0.gcns.0.conv.weight', pre + 'base.5.0.g_q.0.weight', pre + 'base.9.0.g_k.0.weight',
