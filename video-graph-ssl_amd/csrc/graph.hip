@@ -51,13 +51,31 @@ __global__ __launch_bounds__(256) void gram_tile_kernel(const float* __restrict_
     part[((long long)b * gridDim.x + chunk) * (T * T) + threadIdx.x] =
         sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
 }
-__global__ void gram_finish_kernel(const float* __restrict__ part, int nchunk, int TT, int total, float* __restrict__ G) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;       // (b, ij)
-  if (i >= total) return;
-  const int b = i / TT, ij = i - b * TT;
+// One block per clip: its 256 threads are TT outputs x (256 / TT) phases; a phase sums every (256/TT)-th chunk partial with
+// eight loads in flight, the phases are combined through LDS in a fixed order (deterministic).  (One thread per output
+// walking all chunks -- up to 256 dependent loads in a single block -- took 31 us per launch on the 4-clip SimSiam step.)
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ part, int nchunk, int TT,
+                                                          float* __restrict__ G) {
+  __shared__ float sh[256];
+  const int b = blockIdx.x, ij = threadIdx.x % TT, ph = threadIdx.x / TT, nph = 256 / TT;
+  const float* p = part + (long long)b * nchunk * TT + ij;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[((long long)b * nchunk + k) * TT + ij];
-  G[i] = s;
+  int k = ph;
+  for (; k + 7 * nph < nchunk; k += 8 * nph) {
+    float l[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l[u] = p[(long long)(k + u * nph) * TT];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += l[u];
+  }
+  for (; k < nchunk; k += nph) s += p[(long long)k * TT];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  if (ph == 0) {
+    float t = 0.f;
+    for (int q = 0; q < nph; ++q) t += sh[q * TT + ij];
+    G[b * TT + ij] = t;
+  }
 }
 
 // Fallback for node counts other than 2 / 4 / 8: one workgroup per (b,i,j).
@@ -95,8 +113,8 @@ int launch_gram(const float* X, const float* Y, long long B, int C, int T, int H
   if (T == 2) hipLaunchKernelGGL((gram_tile_kernel<2>), grid, dim3(256), 0, st, X, Y, C, HW, cper, ws);
   else if (T == 4) hipLaunchKernelGGL((gram_tile_kernel<4>), grid, dim3(256), 0, st, X, Y, C, HW, cper, ws);
   else hipLaunchKernelGGL((gram_tile_kernel<8>), grid, dim3(256), 0, st, X, Y, C, HW, cper, ws);
-  const int TT = T * T, total = (int)(B * TT);
-  hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0, st, ws, nchunk, TT, total, G);
+  const int TT = T * T;
+  hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)B), dim3(256), 0, st, ws, nchunk, TT, G);      // TT in {4, 16, 64} divides 256
   return gca_launch_status();
 }
 
