@@ -219,6 +219,10 @@ int gca_maxpool3d_fwd(const gca_pool_geom* g, const void* x, void* y, int32_t* a
                       const float* shift, int act_f16, void* stream);
 int gca_maxpool3d_bwd(const gca_pool_geom* g, const void* dy, const int32_t* argmax, void* dx,
                       int accumulate, int act_f16, void* stream);
+/* nn.AvgPool3d(kernel_size=k) (stride = k, no padding, floor mode; fp32 maps): the `max_pool=False` option of
+ * TemporalGraphAug (lib/ops/module_wrappers/temporal_graph.py:100).  Other strides / paddings: GCA_EINVAL. */
+int gca_avgpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, void* stream);
+int gca_avgpool3d_bwd(const gca_pool_geom* g, const float* dy, float* dx, int accumulate, void* stream);
 /* y[n,c] = sum_{d,h,w} wt[d] * x[n,c,d,h,w] * norm   (wt == NULL -> all ones) */
 /* x_f16: the feature map (x, dx) is stored fp16; the pooled features y / dy are fp32 either way (the head is fp32). */
 int gca_wavgpool_fwd(const void* x, const float* wt, float norm, int64_t NC, int64_t D, int64_t HW,
@@ -274,6 +278,10 @@ int gca_moco_logits_bwd(const float* dlogits, const float* logits, const float* 
                         const float* k, const float* queue, int64_t b, int64_t K, int64_t D, float inv_T,
                         int64_t ov_start, const int64_t* ov_start_dev /* overrides ov_start if non-NULL */,
                         int64_t ov_n, const float* ov_rows, float* dq, void* ws, void* stream);
+/* accuracy(output, target, topk) of lib/evaluation/metric.py:44-67 (called at tools/train_video_contrast_dis.py:428) without
+ * the top-k sort or a host sync: rank_ge[i] = number of columns j != target[i] with output[i,j] >= output[i,target[i]];
+ * the target is in the top k of row i iff rank_ge[i] < k.  target must lie in [0, ncol) (not checked on the device). */
+int gca_rank_ge(const float* output, const int64_t* target, int64_t b, int64_t ncol, int32_t* rank_ge, void* stream);
 /* queue[(ptr + i) % K] = keys[i], i < n; optionally saves the overwritten rows first.  The
  * reference keeps the pointer as a Python int (mem_moco.py:12); for hipGraph replay it can live in
  * device memory instead: ptr_dev (non-NULL) overrides ptr, gca_queue_advance moves it. */
@@ -314,16 +322,30 @@ int gca_graph_gcn_bwd(const float* adj, const float* s, const float* dout, int64
  * ------------------------------------------------------------------------------------- */
 int gca_ema_update(float* p_ema, const float* p, int64_t n, float m, void* stream);
 /* seg table: per 256-element chunk i: lr[i], wd[i] (device arrays of length n/256).
- * grad_clip: NULL, or the 2-float result of gca_grad_clip_coef -- every gradient is multiplied by grad_clip[1] on the
- * fly (the grads.mul_(clip_coef) pass of clip_grad_norm_ without a pass over the arena). */
+ * grad_clip: NULL, or the 4-float result of gca_grad_clip_coef / gca_grad_unscale_clip -- every gradient is multiplied by
+ * grad_clip[1] on the fly (the grads.mul_(clip_coef) pass of clip_grad_norm_ without a pass over the arena), and when
+ * grad_clip[2] != 0 (a non-finite gradient under loss scaling) the whole update is skipped: parameters and momentum stay
+ * as they are, as apex amp skips optimizer.step() (tools/train_video_contrast_dis.py:413-419 under APEX.FLAG). */
 int gca_sgd_step(float* p, const float* grad, float* mom_buf, int64_t n, const float* chunk_lr,
                  const float* chunk_wd, float lr_scale, float momentum, int nesterov, int first_step,
                  const float* grad_clip, void* stream);
 /* clip_grad_norm_(parameters, max_norm) of tools/train_video_contrast_dis.py:420-423 over the flat gradient arena
- * (n % 4 == 0; padding elements are zero): out2[0] = total 2-norm, out2[1] = min(1, max_norm / (norm + 1e-6)).
- * fp64 partial sums folded in a fixed order (deterministic); `ws` = gca_grad_clip_ws_bytes() bytes. */
+ * (n % 4 == 0; padding elements are zero): out4[0] = total 2-norm, out4[1] = min(1, max_norm / (norm + 1e-6)),
+ * out4[2] = out4[3] = 0.  fp64 partial sums folded in a fixed order (deterministic); `ws` = gca_grad_clip_ws_bytes() bytes. */
 int64_t gca_grad_clip_ws_bytes(void);
-int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out2, void* ws, void* stream);
+int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out4, void* ws, void* stream);
+/* Dynamic loss scaling for the fp16-storage path -- what `amp.scale_loss(loss, optimizer)` + the patched optimizer.step()
+ * do in the reference (tools/train_video_contrast_dis.py:134-141 amp.initialize, :413-418 scale_loss; apex's LossScaler:
+ * 2x after 2000 clean steps, 0.5x and a skipped step on inf / nan), decided ON THE DEVICE (no host sync, hipGraph-safe):
+ *   scale_state4 = {loss scale S, clean steps in a row, skipped steps, steps seen}; S is read by the loss-gradient kernels
+ *   through their gscale_dev argument (gca_moco_logits_bwd, gca_nce_softmax_loss_bwd, gca_scale_dev).
+ *   out4[0] = 2-norm of grad / S, out4[1] = (1/S) * clip coefficient (max_norm <= 0: no clipping) -- the factor the SGD
+ *   kernel multiplies every gradient by, out4[2] = 1 when any element of grad is inf / nan (then out4[1] = 0, S is
+ *   multiplied by `backoff` and gca_sgd_step leaves parameters and momentum untouched), out4[3] = the S these gradients
+ *   were computed with.  After `growth_interval` clean steps S *= growth (capped at max_scale). `ws`: gca_grad_clip_ws_bytes(). */
+int gca_grad_unscale_clip(const float* grad, int64_t n, float max_norm, float* scale_state4, float growth, float backoff,
+                          int growth_interval, float max_scale, float* out4, void* ws, void* stream);
+int gca_scale_dev(float* y, int64_t n, const float* a_dev, float a_host, void* stream);   /* y *= (*a_dev) * a_host */
 int gca_fill(float* p, int64_t n, float v, void* stream);
 int gca_axpy(float* y, const float* x, int64_t n, float a, void* stream);          /* y += a*x */
 int gca_scale(float* y, int64_t n, float a, void* stream);

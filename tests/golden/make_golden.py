@@ -325,6 +325,36 @@ def gen_graph():
     npz('graph', **out)
 
 
+def gen_graph_options():
+    """The constructor options of TemporalGraphAug the shipped configs never set (temporal_graph.py:66-129): no sub-sampling,
+    average instead of max pooling, BatchNorm behind the similarity convs, and a 3-layer GCN stack with an explicit
+    inter_channels (with the default inter_channels=None the reference itself cannot build more than one layer: :95-98 pass
+    None as in_features).  Whole-block forward + backward under a fixed seed; the uniforms rsample() drew are stored."""
+    out = {}
+    variants = {'nosub': dict(sub_sample=False), 'avg': dict(max_pool=False), 'bn': dict(bn_layer=True),
+                'gcn3': dict(inter_channels=8, num_gcn_layers=3), 'bias': dict(bias=True)}
+    for i, (tag, kw) in enumerate(variants.items()):
+        torch.manual_seed(70 + i)
+        aug = ref_tg.TemporalGraphAug(in_channels=16, **kw)
+        aug.train()
+        for g in aug.gcns:
+            g.conv.weight.data.mul_(0.5)
+        x = torch.randn(3, 16, 4, 6, 6, requires_grad=True)
+        out.update(sd_np(aug, tag + ':w:'))
+        torch.manual_seed(90 + i)
+        y = aug(x)
+        torch.manual_seed(90 + i)
+        u = torch.rand(3, 4, 4)                      # the uniforms rsample() drew (same seed, same shape)
+        dy = torch.randn(y.shape)
+        y.backward(dy)
+        out.update({tag + ':x': x, tag + ':u': u, tag + ':y': y, tag + ':dy': dy, tag + ':dx': x.grad})
+        for n, prm in aug.named_parameters():
+            out[tag + ':g:' + n] = prm.grad
+        if kw.get('bn_layer'):
+            out.update(sd_np(aug, tag + ':after:'))  # running statistics after the forward
+    npz('graph_options', **out)
+
+
 # ------------------------------------------------------------------ 6. SimSiam / step traces / solver
 def gen_steps():
     out = {}

@@ -296,8 +296,11 @@ def test_f16_storage_distance_from_fp32_is_what_storage_rounding_explains(pkg, o
             with pkg.MoCoTrainer(cfg, dev, use_graph=False, seed=1) as tr:
                 out = tr.train_step(x, shuffle_ids=sh)
                 a = tr.arena_q
+                # fp16 storage leaves the arena gradients x the loss scale (the SGD kernel un-scales on the fly): out['grad_norm'][3]
+                inv = 1.0 / float(out['grad_norm'][3]) if mode == 'fp16' else 1.0
+                assert mode != 'fp16' or float(out['grad_norm'][2]) == 0.0           # no overflow, the step was applied
                 res[tag] = dict(q=out['q'].clone(), loss=float(out['loss']),
-                                grads={n: a.grad[o:o + s].clone() for n, o, s in zip(a.names, a.offsets, a.sizes)})
+                                grads={n: a.grad[o:o + s].clone() * inv for n, o, s in zip(a.names, a.offsets, a.sizes)})
     finally:
         ops.set_conv_math(default)
 
@@ -310,3 +313,106 @@ def test_f16_storage_distance_from_fp32_is_what_storage_rounding_explains(pkg, o
     assert qB < 8 * qC and qB < 0.1, (qB, qC)
     assert gB < 4 * gC, (gB, gC)
     assert abs(res['B']['loss'] - res['A']['loss']) < 5e-2 * abs(res['A']['loss'])
+
+
+def test_dynamic_loss_scale_kernels_skip_backoff_and_growth(pkg, ops):
+    """gca_grad_unscale_clip + gca_sgd_step = what apex amp's scale_loss / patched optimizer.step() do in the reference
+    (tools/train_video_contrast_dis.py:134-141,413-418), without a host sync: clean gradients are un-scaled (and clipped)
+    inside the update; ONE inf or nan anywhere skips the update bit for bit, halves the scale and counts the skip;
+    `interval` clean steps in a row double the scale."""
+    torch.manual_seed(3)
+    n = 256 * 1203
+    S0 = 1024.0
+    p0, g0 = torch.randn(n), torch.randn(n) * 0.01
+    lr = torch.full((n // 256,), 0.06, device=DEV)
+    wd = torch.full((n // 256,), 5e-4, device=DEV)
+    saved = ops.LOSS_SCALE_INTERVAL
+    try:
+        ops.LOSS_SCALE_INTERVAL = 3
+        for max_norm in (None, 0.5):
+            state = ops.loss_scale_state(S0, torch.device(DEV))
+            pr = torch.nn.Parameter(p0.clone())
+            opt = torch.optim.SGD([pr], lr=0.06, momentum=0.9, weight_decay=5e-4)
+            pd, buf = p0.to(DEV), torch.zeros(n, device=DEV)
+            scale = S0
+            for step, poison in enumerate((None, None, float('inf'), None, float('nan'), None, None, None, None)):
+                gs = g0 * (step + 1)
+                gd = (gs * scale).to(DEV)                       # what a backward pass seeded with S produces
+                if poison is not None:
+                    gd[n // 3] = poison
+                before_p, before_b = pd.clone(), buf.clone()
+                out = ops.grad_unscale_clip(gd, state, max_norm)
+                ops.sgd_step(pd, gd, buf, lr, wd, 1.0, 0.9, False, out)
+                o, st = out.cpu(), state.cpu()
+                assert float(o[3]) == scale
+                if poison is not None:
+                    assert float(o[2]) == 1.0 and float(o[1]) == 0.0
+                    assert torch.equal(pd, before_p) and torch.equal(buf, before_b)          # optimizer.step() skipped
+                    scale = max(scale * 0.5, 1.0)
+                    clean = 0
+                else:
+                    pr.grad = gs.clone()
+                    if max_norm is not None:
+                        torch.nn.utils.clip_grad_norm_([pr], max_norm)
+                    opt.step()
+                    assert float(o[2]) == 0.0
+                    assert abs(float(o[0]) - float(gs.norm())) < 1e-4 * float(gs.norm())
+                    assert rel_err(pd, pr.data) < 1e-5
+                    clean = int(st[1])
+                assert float(st[0]) in (scale, scale * 2.0)
+                scale = float(st[0])
+            st = state.cpu()
+            assert float(st[2]) == 2.0 and float(st[3]) == 9.0                               # two skipped steps of nine
+            # 2 clean, skip (S/2), 1 clean, skip (S/4), then 4 clean: one doubling after the third of them
+            assert float(st[0]) == S0 / 4 * 2 and float(st[1]) == 1.0
+    finally:
+        ops.LOSS_SCALE_INTERVAL = saved
+
+
+@pytest.mark.parametrize('kind', ['moco', 'simsiam'])
+def test_trainer_skips_the_step_on_fp16_overflow_and_recovers(pkg, ops, kind, monkeypatch):
+    """fp16 storage with a loss scale far too large (2^30: the first activation gradients overflow fp16's 65504): the
+    trainer must NOT write inf / nan into the fp32 master weights, the momentum or the key encoder; it halves the scale per
+    skipped step until the gradients fit, then trains.  hipGraph replay included (the decision lives on the device)."""
+    import parity
+    parity.register_tiny(pkg)
+    monkeypatch.setenv('GCA_LOSS_SCALE', str(2.0 ** 30))
+    default = ops.get_conv_math()
+    ops.set_conv_math('fp16')
+    try:
+        dev = torch.device(DEV)
+        torch.manual_seed(2)
+        x = torch.randn(8, 6, 8, 48, 48, device=dev)
+        if kind == 'moco':
+            tr = pkg.MoCoTrainer(parity.make_cfg(pkg, 'R2P1D10T', 'moco', 32, 64, 8), dev, use_graph=True, seed=4)
+            arena = tr.arena_q
+        else:
+            tr = pkg.SimSiamTrainer(parity.make_cfg(pkg, 'R2P1D10T', 'simsiam', 32, 16, 8), dev, use_graph=True, seed=4)
+            arena = tr.arena
+        p0 = arena.flat.clone()
+        skipped = applied = 0
+        scales = []
+        for step in range(40):
+            before = arena.flat.clone()
+            out = tr.train_step(x)
+            rec = out['grad_norm'].cpu()
+            scales.append(float(rec[3]))
+            assert torch.isfinite(arena.flat).all() and torch.isfinite(tr.optimizer.buf).all(), step
+            if kind == 'moco':
+                assert torch.isfinite(tr.arena_k.flat).all(), step
+            if float(rec[2]) != 0.0:
+                skipped += 1
+                assert torch.equal(arena.flat, before), step               # skipped: the query encoder is untouched
+            else:
+                applied += 1
+                assert not torch.equal(arena.flat, before), step
+            if applied >= 4:
+                break
+        st = tr.scale_state.cpu()
+        assert skipped >= 5 and applied >= 4, (skipped, applied, scales)
+        assert float(st[2]) == skipped and float(st[0]) == 2.0 ** 30 / 2.0 ** skipped, (st, skipped)
+        assert torch.isfinite(out['loss']).all()
+        assert tr._segments[0].graph is not None                           # the later steps were hipGraph replays
+        tr.close()
+    finally:
+        ops.set_conv_math(default)

@@ -436,3 +436,113 @@ def _full_width_backward(pkg, name, math):
     else:
         parity.check_grad_errors(errs)
         assert parity.rel(dx, x64.grad) < 2e-2
+
+
+@pytest.mark.parametrize('tag,kw', [('nosub', dict(sub_sample=False)), ('avg', dict(max_pool=False)), ('bn', dict(bn_layer=True)),
+                                    ('gcn3', dict(inter_channels=8, num_gcn_layers=3)), ('bias', dict(bias=True))])
+def test_temporal_graph_block_constructor_options_golden(pkg, golden, tag, kw):
+    """The TemporalGraphAug options no shipped config sets (temporal_graph.py:66-129): no sub-sampling, average pooling,
+    BatchNorm behind the similarity convs, a 3-layer GCN stack, biased similarity convs -- whole-block forward + backward
+    against the REFERENCE's own class (tests/golden/make_golden.py gen_graph_options), state-dict keys included."""
+    g = golden('graph_options')
+    tg = pkg.lib.ops.module_wrappers.temporal_graph
+    aug = tg.TemporalGraphAug(in_channels=16, **kw)
+    w = g.group(tag + ':w:')
+    assert sorted(aug.state_dict().keys()) == sorted(w.keys())
+    aug.load_state_dict(w)
+    aug.to(DEV).train()
+    aug.noise = g.t(tag + ':u').to(DEV)
+    y, dx = _run(pkg, aug, g.t(tag + ':x').to(DEV), dy=g.t(tag + ':dy').to(DEV))
+    assert rel_err(y, g.t(tag + ':y')) < 1e-4
+    assert rel_err(dx, g.t(tag + ':dx')) < 1e-3
+    grads = g.group(tag + ':g:')
+    for n, p in aug.named_parameters():
+        scale = max(float(grads[n].abs().max()), 1e-6)
+        assert float((p.grad.cpu() - grads[n]).abs().max()) < 1e-3 * scale + 1e-7, n
+    if tag == 'bn':
+        after = g.group(tag + ':after:')
+        for k_, v in aug.state_dict().items():
+            if 'running' in k_:
+                assert rel_err(v, after[k_]) < 1e-4, k_
+    with pytest.raises(NotImplementedError):
+        tg.TemporalGraphAug(16, mask_frame=True)
+    with pytest.raises(ValueError):
+        tg.TemporalGraphAug(16, num_gcn_layers=2)
+
+
+def test_reference_metric_api_accuracy_and_average_meter(pkg):
+    """accuracy(output, target, topk) / AverageMeter with the reference's signatures (lib/evaluation/metric.py:9-24,44-67; the
+    call of tools/train_video_contrast_dis.py:428) against the oracle's restatement of the top-k form, on InfoNCE-shaped
+    logits (label 0) and on arbitrary labels, without leaving the device."""
+    from oracle import moco as omoco
+    ev = pkg.lib.evaluation
+    torch.manual_seed(4)
+    for b, ncol in ((32, 4097), (7, 65537), (5, 11)):
+        out = torch.randn(b, ncol)
+        out[:, 0] += 2.5                                   # some rows have the label on top, some do not
+        for target in (torch.zeros(b, dtype=torch.long), torch.randint(0, ncol, (b,))):
+            want = omoco.accuracy(out, target, topk=(1, 5))
+            got = ev.accuracy(out.to(DEV), target.to(DEV), topk=(1, 5))
+            assert all(g_.is_cuda and g_.shape == (1,) for g_ in got)
+            assert [round(float(g_), 4) for g_ in got] == [round(float(w_), 4) for w_ in want], (b, ncol)
+        _, _, rank = pkg.engine.ops.moco_logits_fwd(torch.nn.functional.normalize(torch.randn(b, 128)).to(DEV),
+                                                    torch.nn.functional.normalize(torch.randn(b, 128)).to(DEV),
+                                                    torch.nn.functional.normalize(torch.randn(ncol - 1, 128)).to(DEV), 1 / 0.07,
+                                                    want_rank=True)
+        assert len(ev.accuracy_from_rank(rank, (1, 5))) == 2
+    m = ev.AverageMeter()
+    m.update(3.0, 2); m.update(torch.tensor([6.0], device=DEV), 1)
+    assert abs(float(m.avg) - 4.0) < 1e-6 and m.count == 3 and float(m.val) == 6.0
+    with pytest.raises(ValueError):
+        ev.accuracy(torch.randn(4, 5, 6).to(DEV), torch.zeros(4, dtype=torch.long).to(DEV))
+
+
+@pytest.mark.parametrize('backbone,T', [('R2P1D10T', 8), ('S3D', 16)])
+def test_dropout_branch_of_prepare_video_model(pkg, backbone, T):
+    """MODEL.DROPOUT > 0 (visual_wrappers.py:109-110: the backbone's fc becomes nn.Dropout; it is also get_defaults()' value,
+    0.5): the model builds, trains and -- with the same keep mask -- equals the oracle wrapper.  torch's device generator
+    draws the mask, so the check re-seeds it and replays the draw."""
+    from oracle import wrappers as owrap
+    parity.register_tiny(pkg)
+    cfg = parity.make_cfg(pkg, backbone, 'moco', 32, 64, T)
+    cfg.MODEL.DROPOUT = 0.5
+    torch.manual_seed(9)
+    model, ema = pkg.create_visual_model(cfg)
+    fc = model.model.encoder.base_model.fc
+    assert isinstance(fc, nn.Dropout) and fc.p == 0.5
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    size = 48 if backbone != 'S3D' else 64
+    x = torch.randn(4, 3, T, size, size)
+    torch.manual_seed(77)
+    q = model(x.to(DEV))
+    q.sum().backward()
+    # the oracle with the SAME mask: replay the device draw
+    torch.manual_seed(77)
+    C = model.model.encoder.feature_dim
+    shape = (4, C) if backbone != 'S3D' else (4, C, 1)       # S3D at 16 x 64 x 64: T' = 2 -> one (2,H,W) window per channel
+    mask = (torch.empty(shape, device=DEV).bernoulli_(0.5) * 2.0).cpu()
+    ref, _ = owrap.create_visual_model(backbone, T, 32, 'mlp', 'moco', dropout=0.5)
+    ref.load_state_dict(sd)
+    ref.double().train()
+
+    class FixedMask(nn.Module):
+        def forward(self, t):
+            return t * mask.double().reshape(t.shape)
+    ref.model.encoder.base_model.fc = FixedMask()
+    qr = ref(x.double())
+    qr.sum().backward()
+    assert rel_err(q, qr) < 1e-3
+    gr = dict(ref.named_parameters())
+    errs = [parity.rel(p.grad, gr[n].grad) for n, p in model.named_parameters() if float(gr[n].grad.abs().max()) > 0]
+    assert sorted(errs)[len(errs) // 2] < 1e-3
+    # eval mode: dropout is the identity
+    model.eval()
+    ref.eval()
+    ref.model.encoder.base_model.fc = nn.Identity()
+    with torch.no_grad():
+        assert rel_err(model(x.to(DEV)), ref(x.double())) < 1e-3
+    # and the default config (DROPOUT 0.5, no YAML) now constructs
+    d = pkg.get_defaults()
+    d.merge_from_list(['MODEL.BACKBONE', 'R2P1D10T', 'CONTRAST.MEM_TYPE', 'moco'])
+    assert isinstance(pkg.create_visual_model(d)[0].model.encoder.base_model.fc, nn.Dropout)

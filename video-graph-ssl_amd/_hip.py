@@ -74,6 +74,8 @@ SIGNATURES = {
                            c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'gca_maxpool3d_fwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     'gca_maxpool3d_bwd': (c_i32, [_PP, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    'gca_avgpool3d_fwd': (c_i32, [_PP, c_vp, c_vp, c_vp]),
+    'gca_avgpool3d_bwd': (c_i32, [_PP, c_vp, c_vp, c_i32, c_vp]),
     'gca_wavgpool_fwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),
     'gca_wavgpool_bwd': (c_i32, [c_vp, c_vp, c_f32, c_i64, c_i64, c_i64, c_vp, c_i32, c_vp]),
     'gca_relu_fwd': (c_i32, [c_vp, c_i64, c_vp, c_vp]),
@@ -101,6 +103,9 @@ SIGNATURES = {
     'gca_sgd_step': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp]),
     'gca_grad_clip_ws_bytes': (c_i64, []),
     'gca_grad_clip_coef': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    'gca_rank_ge': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'gca_grad_unscale_clip': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    'gca_scale_dev': (c_i32, [c_vp, c_i64, c_vp, c_f32, c_vp]),
     'gca_fill': (c_i32, [c_vp, c_i64, c_f32, c_vp]),
     'gca_axpy': (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     'gca_scale': (c_i32, [c_vp, c_i64, c_f32, c_vp]),

@@ -672,6 +672,22 @@ __global__ void queue_advance_kernel(long long* ptr_dev, long long n, long long 
   if (threadIdx.x == 0 && blockIdx.x == 0) *ptr_dev = (*ptr_dev + n) % K;
 }
 
+
+// accuracy(output, target, topk) of lib/evaluation/metric.py:44-67 without its top-k sort: the target column is among the
+// top k of its row iff fewer than k OTHER columns score >= it (the same ">= the positive" counter the logits kernel fuses
+// for label 0).  One workgroup per row.
+__global__ __launch_bounds__(256) void rank_ge_kernel(const float* __restrict__ out, const long long* __restrict__ target,
+                                                      long long ncol, int* __restrict__ rank) {
+  __shared__ float sh[4];
+  const long long i = blockIdx.x;
+  const long long t = target[i];
+  const float* row = out + i * ncol;
+  const float ref = row[t];
+  float c = 0.f;
+  for (long long j = threadIdx.x; j < ncol; j += 256) c += (j != t && row[j] >= ref) ? 1.f : 0.f;
+  c = gca_block_sum256(c, sh);
+  if (threadIdx.x == 0) rank[i] = (int)(c + 0.5f);
+}
 }  // namespace
 
 extern "C" {
@@ -823,6 +839,13 @@ int gca_queue_enqueue(float* queue, int64_t K, int64_t D, const float* keys, int
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(enqueue_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, queue, (long long)K,
                      (int)D, keys, (long long)n, (long long)ptr, (const long long*)ptr_dev, saved_rows);
+  return gca_launch_status();
+}
+
+int gca_rank_ge(const float* output, const int64_t* target, int64_t b, int64_t ncol, int32_t* rank_ge, void* stream) {
+  if (!output || !target || !rank_ge || b <= 0 || ncol <= 0 || ncol >= (1LL << 24)) return GCA_EINVAL;   // (exact fp32 counts)
+  hipLaunchKernelGGL(rank_ge_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, output, (const long long*)target,
+                     (long long)ncol, rank_ge);
   return gca_launch_status();
 }
 

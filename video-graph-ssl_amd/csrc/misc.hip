@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const f
                                                   float lr_scale, float mom, int nesterov, int first,
                                                   const float* __restrict__ gscale) {
   const float gs = gscale ? gscale[1] : 1.f;       // clip coefficient of gca_grad_clip_coef (grads.mul_(coef) folded in)
+  if (gscale && gscale[2] != 0.f) return;          // a non-finite gradient was found (gca_grad_unscale_clip): optimizer.step() is skipped
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
     const long long c = i >> 6;
     const float lr = clr[c] * lr_scale, wd = cwd[c];
@@ -148,7 +149,45 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     const float tn = (float)sqrt(s);
     out[0] = tn;
     out[1] = fminf(max_norm / (tn + 1e-6f), 1.0f);
+    out[2] = 0.f;                                   // (torch's clip_grad_norm_ does not skip on a non-finite norm: neither does this)
+    out[3] = 0.f;
   }
+}
+
+// Dynamic loss scaling (the reference's apex amp, tools/train_video_contrast_dis.py:134-141,413-418: scaled loss, un-scaled
+// gradients, optimizer.step() skipped and the scale halved when a gradient is inf / nan, scale doubled after
+// `interval` clean steps), decided on the device from the same fp64 sum of squares the clip uses: a non-finite element
+// makes the sum non-finite.  state = {scale S, clean steps in a row, skipped steps so far, steps seen}.
+__global__ __launch_bounds__(256) void unscale_clip_kernel(const double* __restrict__ part, int nparts, float max_norm,
+                                                           float* __restrict__ state, float growth, float backoff,
+                                                           int interval, float max_scale, float* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = gca_block_sum256_d(s, sh);
+  if (threadIdx.x == 0) {
+    float S = state[0];
+    const bool finite = s == s && s < 1.7e308 && s >= 0.0;
+    if (finite) {
+      const float tn = (float)(sqrt(s) / (double)S);            // norm of the UN-scaled gradient
+      const float coef = max_norm > 0.f ? fminf(max_norm / (tn + 1e-6f), 1.0f) : 1.0f;
+      out[0] = tn; out[1] = coef / S; out[2] = 0.f; out[3] = S;
+      const float clean = state[1] + 1.f;
+      if (interval > 0 && clean >= (float)interval) { S = fminf(S * growth, max_scale); state[1] = 0.f; }
+      else state[1] = clean;
+    } else {
+      out[0] = __builtin_inff(); out[1] = 0.f; out[2] = 1.f; out[3] = S;
+      S = fmaxf(S * backoff, 1.f);
+      state[1] = 0.f;
+      state[2] += 1.f;
+    }
+    state[0] = S;
+    state[3] += 1.f;
+  }
+}
+__global__ void scale_dev_kernel(float* __restrict__ y, long long n, const float* __restrict__ a_dev, float a_host) {
+  const float a = (a_dev ? *a_dev : 1.f) * a_host;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] *= a;
 }
 
 __global__ void fill_kernel(float* __restrict__ p, long long n, float v) {
@@ -243,7 +282,8 @@ int gca_sgd_step(float* p, const float* grad, float* mom_buf, int64_t n, const f
   return gca_launch_status();
 }
 int64_t gca_grad_clip_ws_bytes(void) { return (int64_t)CLIP_BLOCKS * (int64_t)sizeof(double); }
-int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out2, void* ws, void* stream) {
+int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out4, void* ws, void* stream) {
+  float* out2 = out4;
   if (!grad || !out2 || !ws || n <= 0 || (n & 3) || !(max_norm > 0.f)) return GCA_EINVAL;
   long long blocks = gca_ceil_div(n / 4, 256 * 8);
   if (blocks > CLIP_BLOCKS) blocks = CLIP_BLOCKS;
@@ -252,6 +292,25 @@ int gca_grad_clip_coef(const float* grad, int64_t n, float max_norm, float* out2
                      reinterpret_cast<double*>(ws));
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double*>(ws),
                      (int)blocks, max_norm, out2);
+  return gca_launch_status();
+}
+int gca_grad_unscale_clip(const float* grad, int64_t n, float max_norm, float* scale_state4, float growth, float backoff,
+                          int growth_interval, float max_scale, float* out4, void* ws, void* stream) {
+  if (!grad || !out4 || !scale_state4 || !ws || n <= 0 || (n & 3) || !(growth >= 1.f) || !(backoff > 0.f && backoff <= 1.f) ||
+      growth_interval < 0 || !(max_scale >= 1.f))
+    return GCA_EINVAL;
+  long long blocks = gca_ceil_div(n / 4, 256 * 8);
+  if (blocks > CLIP_BLOCKS) blocks = CLIP_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sqsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, (long long)(n / 4),
+                     reinterpret_cast<double*>(ws));
+  hipLaunchKernelGGL(unscale_clip_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const double*>(ws),
+                     (int)blocks, max_norm, scale_state4, growth, backoff, growth_interval, max_scale, out4);
+  return gca_launch_status();
+}
+int gca_scale_dev(float* y, int64_t n, const float* a_dev, float a_host, void* stream) {
+  if (!y || n <= 0) return GCA_EINVAL;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, y, (long long)n, a_dev, a_host);
   return gca_launch_status();
 }
 int gca_fill(float* p, int64_t n, float v, void* stream) {

@@ -306,6 +306,36 @@ inline bool pool_ok(const gca_pool_geom* g) {
   return g->OD > 0 && g->OH > 0 && g->OW > 0;
 }
 
+
+// nn.AvgPool3d(kernel_size=k) with its default stride = k and no padding (temporal_graph.py:100, the max_pool=False option
+// of TemporalGraphAug): windows do not overlap, trailing rows / columns that do not fill a window are dropped (floor mode).
+__global__ __launch_bounds__(256) void avgpool3d_fwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ x,
+                                                            float* __restrict__ y, unsigned total) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= total) return;
+  const unsigned plane = gca_fdiv(i, q.osp), o = i - plane * q.osp.d;
+  const int od = (int)gca_fdiv(o, q.ohw), r = (int)(o - (unsigned)od * q.ohw.d);
+  const int oh = (int)gca_fdiv((unsigned)r, q.ow), ow = r - oh * g.OW;
+  const float* xp = x + (long long)plane * ((long long)g.D * g.H * g.W);
+  float s = 0.f;
+  for (int a = 0; a < g.kd; ++a)
+    for (int b = 0; b < g.kh; ++b)
+      for (int c = 0; c < g.kw; ++c) s += xp[((od * g.kd + a) * g.H + oh * g.kh + b) * g.W + ow * g.kw + c];
+  y[i] = s / (float)(g.kd * g.kh * g.kw);
+}
+__global__ __launch_bounds__(256) void avgpool3d_bwd_kernel(gca_pool_geom g, PoolMagic q, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, unsigned total, int accumulate) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;          // one thread per INPUT element: at most one window covers it
+  if (i >= total) return;
+  const unsigned plane = gca_fdiv(i, q.sp), e = i - plane * q.sp.d;
+  const int d = (int)gca_fdiv(e, q.hw), r = (int)(e - (unsigned)d * q.hw.d);
+  const int h = (int)gca_fdiv((unsigned)r, q.w), w = r - h * g.W;
+  const int od = d / g.kd, oh = h / g.kh, ow = w / g.kw;
+  float v = 0.f;
+  if (od < g.OD && oh < g.OH && ow < g.OW)
+    v = dy[(long long)plane * ((long long)g.OD * g.OH * g.OW) + ((long long)od * g.OH + oh) * g.OW + ow] / (float)(g.kd * g.kh * g.kw);
+  dx[i] = accumulate ? dx[i] + v : v;
+}
 }  // namespace
 
 extern "C" {
@@ -411,6 +441,26 @@ int gca_maxpool3d_bwd(const gca_pool_geom* g, const void* dy, const int32_t* arg
   else if (cd == 1 && ch == 1 && cw == 1) GCA_POOL_BWD(1, 1, 1);
   else GCA_POOL_BWD(0, 0, 0);
 #undef GCA_POOL_BWD
+  return gca_launch_status();
+}
+
+static bool avgpool_ok(const gca_pool_geom* g) {
+  return pool_ok(g) && g->sd == g->kd && g->sh == g->kh && g->sw == g->kw && g->pd == 0 && g->ph == 0 && g->pw == 0;
+}
+int gca_avgpool3d_fwd(const gca_pool_geom* g, const float* x, float* y, void* stream) {
+  if (!avgpool_ok(g) || !x || !y) return GCA_EINVAL;
+  const long long total = (long long)g->N * g->C * g->OD * g->OH * g->OW;
+  if (total >= (1LL << 31) || (long long)g->D * g->H * g->W >= (1LL << 31)) return GCA_EINVAL;
+  hipLaunchKernelGGL(avgpool3d_fwd_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, *g,
+                     pool_magic(g), x, y, (unsigned)total);
+  return gca_launch_status();
+}
+int gca_avgpool3d_bwd(const gca_pool_geom* g, const float* dy, float* dx, int accumulate, void* stream) {
+  if (!avgpool_ok(g) || !dy || !dx) return GCA_EINVAL;
+  const long long total = (long long)g->N * g->C * g->D * g->H * g->W;
+  if (total >= (1LL << 31)) return GCA_EINVAL;
+  hipLaunchKernelGGL(avgpool3d_bwd_kernel, dim3((unsigned)gca_ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, *g,
+                     pool_magic(g), dy, dx, (unsigned)total, accumulate ? 1 : 0);
   return gca_launch_status();
 }
 

@@ -33,12 +33,18 @@ class _PackedWeight(object):
 
     def _init_pack(self):
         self._pack, self._pack_plan, self._prepacked = [None, None], [None, None], [False, False]
+        self._pack_layout = [None, None]      # gca_conv_pack_layout() the buffer was last written in
 
     def packed(self, plan, which):
         if self._prepacked[which] and self._pack_plan[which] is plan:
+            # plans are shared per geometry: if a launch-tuning decision moved this class to another packed layout after
+            # the batched pack was planned, the buffer no longer holds what the kernel will read
+            if ops.H.lib.gca_conv_pack_layout(plan.gp, which) != self._pack_layout[which]:
+                raise RuntimeError('packed weights are in a stale layout for this plan; rebuild the BatchedPacker')
             return self._pack[which]
         self._pack[which] = ops.conv_pack(plan, which, self.weight.data, self._pack[which])
         self._pack_plan[which] = plan
+        self._pack_layout[which] = ops.H.lib.gca_conv_pack_layout(plan.gp, which)
         return self._pack[which]
 
 
@@ -65,6 +71,7 @@ class BatchedPacker(object):
                 if H.lib.gca_conv_pack_jobs_host(plan.gp, which, m.weight.data_ptr(), buf.data_ptr(), raw) != n:
                     raise RuntimeError('gca_conv_pack_jobs_host failed')
                 recs.append(raw.raw)
+                m._pack_layout[which] = H.lib.gca_conv_pack_layout(plan.gp, which)     # what these jobs write
                 self.layers.append((m, which, plan, buf))
                 dev = buf.device
         blob = ctypes.create_string_buffer(b''.join(recs))
@@ -164,6 +171,16 @@ class HipMaxPool3d(nn.Module):
         self.padding = t3(padding)
 
 
+class HipAvgPool3d(nn.Module):
+    """nn.AvgPool3d(kernel_size) with its default stride (= kernel size) and no padding."""
+
+    def __init__(self, kernel_size):
+        super().__init__()
+        t3 = lambda v: (v, v, v) if isinstance(v, int) else tuple(v)
+        self.kernel_size = self.stride = t3(kernel_size)
+        self.padding = (0, 0, 0)
+
+
 class HipReLU(nn.Module):
     def __init__(self, inplace=False):
         super().__init__()
@@ -199,6 +216,10 @@ def f_seq(tape, module, xv):
         return module.fwd(tape, xv)
     if isinstance(module, HipMaxPool3d):
         return f_maxpool(tape, module, xv)
+    if isinstance(module, HipAvgPool3d):
+        return f_avgpool(tape, module, xv)
+    if isinstance(module, HipConv3d):
+        return f_conv(tape, module, xv)
     if isinstance(module, nn.Sequential):
         for m in module:
             xv = f_seq(tape, m, xv)
@@ -402,6 +423,65 @@ def f_maxpool(tape, pool, xv):
     return yv
 
 
+def f_avgpool(tape, pool, xv):
+    x = xv.t
+    plan = ops.pool_plan(tuple(x.shape), pool.kernel_size, pool.stride, pool.padding)
+    yv = Var(ops.avgpool_fwd(plan, x), tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            buf, acc = xv.grad_buffer()
+            ops.avgpool_bwd(plan, yv.grad, buf, acc)
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
+def f_dropout(tape, drop, xv):
+    """nn.Dropout on the pooled (N, C) features (visual_wrappers.py:109-110, MODEL.DROPOUT > 0).  The keep mask is drawn
+    by torch's generator on the device (as nn.Dropout does: reproducible under torch.manual_seed); mask and 1/(1-p)
+    scaling are one elementwise product -- a (N, C) tensor of a few KB, not a hot-path kernel."""
+    if drop.p == 0 or not drop.training:
+        return xv
+    x = xv.t
+    if drop.p >= 1:
+        mask = torch.zeros_like(x)
+    else:
+        mask = torch.empty_like(x).bernoulli_(1.0 - drop.p).mul_(1.0 / (1.0 - drop.p))
+    yv = Var(x * mask, tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            xv.add_grad(yv.grad * mask)
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
+def f_s3d_tail_with_dropout(tape, drop, xv):
+    """S3D's tail when its `fc` has been replaced by nn.Dropout (MODEL.DROPOUT > 0, visual_wrappers.py:109-110):
+    avg_pool3d((2,H,W), stride 1) -> dropout on the (B,C,T-1,1,1) map -> mean over time (s3d_1.py:30-33).  The spatial
+    means come from the pooling kernel; the (B,C,T) remainder is a few KB of elementwise work."""
+    x = xv.t
+    N, C, T, Hh, W = x.shape
+    m = ops.wavgpool_fwd(x.view(N, C * T, 1, Hh, W), None, 1.0 / (Hh * W)).view(N, C, T)
+    pooled = 0.5 * (m[:, :, :-1] + m[:, :, 1:])
+    keep = 1.0 - drop.p
+    mask = torch.empty_like(pooled).bernoulli_(keep).mul_(1.0 / keep) if keep > 0 else torch.zeros_like(pooled)
+    yv = Var((pooled * mask).mean(2), tape.recording)
+
+    def back():
+        if xv.needs_grad:
+            dp = yv.grad[:, :, None] * mask * (0.5 / (T - 1))
+            dm = torch.zeros((N, C, T), dtype=torch.float32, device=x.device)
+            dm[:, :, :-1] += dp
+            dm[:, :, 1:] += dp
+            xv.add_grad(ops.wavgpool_bwd(dm.view(N, C * T), None, 1.0 / (Hh * W), (N, C * T, 1, Hh, W), x.dtype).view(x.shape))
+        yv.grad = None
+    tape.record(back)
+    return yv
+
+
 def f_wavgpool(tape, xv, wt=None, norm=None):
     """(N,C,D,H,W) -> (N,C): norm * sum_d wt[d] * sum_hw x.  Global mean when wt is None."""
     x = xv.t
@@ -438,7 +518,5 @@ def f_head_fc(tape, fc, xv):
     if isinstance(fc, HipLinear):
         return f_linear(tape, fc, xv)
     if isinstance(fc, nn.Dropout):
-        if fc.p == 0 or not fc.training:
-            return xv
-        raise NotImplementedError('dropout > 0 is not used by the pre-training configs (DROPOUT: 0.)')
+        return f_dropout(tape, fc, xv)
     raise TypeError('unsupported head module %r' % type(fc))

@@ -309,10 +309,18 @@ class ConvPlan:
         layout0 = layout()
         if hit is not None:
             apply(hit)
-            if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0 and (repack is not None or layout() == layout0):
-                if repack is not None and layout() != layout0:
+            if H.lib.gca_conv_fwd_stat_parts(self.gp) >= 0:
+                if layout() == layout0:
+                    return                                         # still a valid launch code for this library
+                if repack is not None:
                     repack()
-                return                                             # still a valid launch code for this library
+                    return
+                # The measured configuration reads another packed layout and this caller cannot re-pack (no raw weights:
+                # the plain HipConv3d.forward path).  Run on the heuristic shape of the layout at hand and leave BOTH the
+                # cache entry and the plan's "untuned" state alone: the next caller that can re-pack adopts the entry.
+                apply((0, 0, 0, 0, 0) if which < 2 else (0, 0, 0))
+                self.tuned[which] = False
+                return
             apply((0, 0, 0, 0, 0) if which < 2 else (0, 0, 0))
         if which == 0:
             cands = [c + (0,) for c in self._igemm_candidates(K, N * OD * OH * OW, g.C * self.taps)]
@@ -585,6 +593,21 @@ def maxpool_bwd(plan, dy, argmax, dx=None, accumulate=False):
     return dx
 
 
+def avgpool_fwd(plan, x):
+    """nn.AvgPool3d(kernel_size=k) (stride k, no padding) on fp32 maps."""
+    y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    H.call('gca_avgpool3d_fwd', plan.gp, ptr(x), ptr(y), stream())
+    return y
+
+
+def avgpool_bwd(plan, dy, dx=None, accumulate=False):
+    if dx is None:
+        dx = torch.empty(plan.in_shape, dtype=F32, device=dy.device)
+        accumulate = False
+    H.call('gca_avgpool3d_bwd', plan.gp, ptr(dy), ptr(dx), int(accumulate), stream())
+    return dx
+
+
 def wavgpool_fwd(x, wt, norm):
     N, Cc, D, Hh, W = x.shape
     y = torch.empty((N, Cc), dtype=F32, device=x.device)
@@ -641,8 +664,13 @@ _NCE_SYNC = {}
 
 
 def _nce_sync(device):
-    """The zero-initialised device counter of the single-launch InfoNCE forward (one per device; every call leaves it 0)."""
-    key = (device.type, device.index)
+    """The zero-initialised ticket counter of the single-launch InfoNCE forward.  Every call leaves it at zero (the last
+    workgroup re-arms it; the GCA_NCE_DEBUG early exits either draw no ticket at all or re-arm it too), and calls on ONE
+    stream are ordered, so a counter may be shared exactly by the calls that already share a scratch buffer: one per
+    (device, scratch lane).  Work issued on a second stream must run under its own lane (ops.WS_LANE, as the trainers' key
+    encoder does) -- that rule already holds for every workspace user (the partials of this kernel live in WS.get), and with
+    it two concurrent RGBMoCo.forward calls never interleave their tickets."""
+    key = (device.type, device.index, WS_LANE[0])
     c = _NCE_SYNC.get(key)
     if c is None:
         c = _NCE_SYNC[key] = torch.zeros(16, dtype=torch.int32, device=device)
@@ -759,12 +787,40 @@ def sgd_step(p, g, buf, chunk_lr, chunk_wd, lr_scale, momentum, nesterov, grad_c
 
 
 def grad_clip_coef(g, max_norm, out=None):
-    """clip_grad_norm_ over the flat gradient arena -> device tensor (total_norm, clip coefficient)."""
+    """clip_grad_norm_ over the flat gradient arena -> device tensor (total_norm, clip coefficient, 0, 0)."""
     if out is None:
-        out = torch.empty(2, dtype=F32, device=g.device)
+        out = torch.empty(4, dtype=F32, device=g.device)
     ws = WS.get(H.lib.gca_grad_clip_ws_bytes(), g.device)
     H.call('gca_grad_clip_coef', ptr(g), g.numel(), float(max_norm), ptr(out), ptr(ws), stream())
     return out
+
+
+# Dynamic loss scaling of the fp16-storage path (apex amp's LossScaler defaults: x2 after 2000 clean steps, x0.5 and a
+# skipped optimizer step on inf / nan, scale capped at 2^24), kept on the device: see gca_grad_unscale_clip.
+LOSS_SCALE_GROWTH, LOSS_SCALE_BACKOFF, LOSS_SCALE_INTERVAL, LOSS_SCALE_MAX = 2.0, 0.5, 2000, 2.0 ** 24
+# The (scale, clean steps, skipped steps, steps) state of the trainer that is running its step, or None for fp32 storage:
+# loss-gradient seeds inside the models (SimSiam's negative cosine) multiply by its first element.
+LOSS_SCALE_STATE = [None]
+
+
+def loss_scale_state(initial, device):
+    return torch.tensor([float(initial), 0.0, 0.0, 0.0], dtype=F32, device=device)
+
+
+def grad_unscale_clip(g, state, max_norm=None, out=None):
+    """Un-scale (by the device-resident loss scale in `state`), overflow-check and clip the flat gradient arena without
+    touching it: -> device tensor (norm of g / S, factor for the SGD kernel, skip flag, S); `state` is advanced."""
+    if out is None:
+        out = torch.empty(4, dtype=F32, device=g.device)
+    ws = WS.get(H.lib.gca_grad_clip_ws_bytes(), g.device)
+    H.call('gca_grad_unscale_clip', ptr(g), g.numel(), float(max_norm or 0.0), ptr(state), LOSS_SCALE_GROWTH,
+           LOSS_SCALE_BACKOFF, int(LOSS_SCALE_INTERVAL), LOSS_SCALE_MAX, ptr(out), ptr(ws), stream())
+    return out
+
+
+def scale_dev_(y, a_dev, a_host=1.0):
+    """y *= a_dev[0] * a_host (a device-resident factor: the loss scale)."""
+    H.call('gca_scale_dev', ptr(y), y.numel(), ptr(a_dev), float(a_host), stream())
 
 
 def fill(t, v):

@@ -132,10 +132,13 @@ class _TrainerBase(object):
 
 
 def _loss_scale():
-    """Static loss scale of the fp16-storage path (a power of two: scaling and un-scaling are exact in fp32; the
-    activation gradients, stored fp16, stay clear of the subnormal range).  1 for fp32 storage."""
+    """INITIAL loss scale of the fp16-storage path (a power of two: scaling and un-scaling are exact in fp32; the
+    activation gradients, stored fp16, stay clear of the subnormal range).  From there the scale is dynamic, as apex amp's
+    is in the reference (tools/train_video_contrast_dis.py:134-141,413-418): a step whose gradients hold an inf / nan is
+    skipped and halves it, 2000 clean steps double it -- all decided on the device (ops.grad_unscale_clip).  None for
+    fp32 storage."""
     if not ops.ACT_F16[0]:
-        return 1.0
+        return None
     s = float(os.environ.get('GCA_LOSS_SCALE', '1024'))
     if s <= 0 or math.frexp(s)[0] != 0.5:
         raise ValueError('GCA_LOSS_SCALE must be a positive power of two, got %r' % s)
@@ -147,8 +150,11 @@ class MoCoTrainer(_TrainerBase):
         _check_unsupported(cfg)
         self.cfg, self.device = cfg, torch.device(device)
         self.clip = clip_value_of(cfg)
-        self.loss_scale = _loss_scale()
         self.ctx = ctx or par.DistCtx()
+        ls = _loss_scale()
+        # fp16 storage: (scale, clean steps in a row, skipped steps, steps) on the device; None for fp32 storage
+        self.scale_state = None if ls is None else ops.loss_scale_state(ls, torch.device(device))
+        self.loss_scale = 1.0 if ls is None else ls           # the INITIAL scale (the live one is scale_state[0], on the device)
         if seed is not None:
             torch.manual_seed(seed)
         self.model, self.model_ema = create_visual_model(cfg)
@@ -241,7 +247,8 @@ class MoCoTrainer(_TrainerBase):
         saved = ops.queue_enqueue(mem, s['all_k'], 0, save=True, ptr_dev=self.ptr_dev)
         # DDP averages gradients: fold 1/world into the loss-gradient scale
         qv.grad = ops.moco_logits_bwd(s['k'], mem, self.inv_T, logits=logits, lse=lse,
-                                      gscale_host=self.loss_scale / self.ctx.world, ov_rows=saved, ov_start_dev=self.ptr_dev)
+                                      gscale_dev=self.scale_state, gscale_host=1.0 / self.ctx.world, ov_rows=saved,
+                                      ov_start_dev=self.ptr_dev)
         ops.queue_advance(self.ptr_dev, s['all_k'].shape[0], self.K)
         self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
         tape.backward(upto)
@@ -257,9 +264,15 @@ class MoCoTrainer(_TrainerBase):
 
     def _phase_update(self):
         clip = None
-        if self.loss_scale != 1.0:                                            # fp16 storage: gradients were computed x S
-            ops.scale_(self.arena_q.grad, 1.0 / self.loss_scale)
-        if self.clip is not None:                                             # :420-423, after the gradient all-reduce
+        if self.scale_state is not None:
+            # fp16 storage: the gradients were computed x S.  One pass over the arena yields the un-scaled norm, the factor
+            # (clip coefficient / S) the SGD kernel applies on the fly and the overflow verdict: inf / nan anywhere -> the
+            # optimizer step is skipped (parameters and momentum untouched) and S is halved, as amp does.  The EMA below
+            # still runs: the reference's _momentum_update is its own call, which amp does not patch (:440).
+            clip = ops.grad_unscale_clip(self.arena_q.grad, self.scale_state, self.clip)
+            self.out['grad_norm'] = clip
+            self.out['loss_scale'] = self.scale_state
+        elif self.clip is not None:                                           # :420-423, after the gradient all-reduce
             clip = self.optimizer.clip_grad_norm(self.clip)
             self.out['grad_norm'] = clip
         self.optimizer.step(grad_clip=clip)
@@ -356,12 +369,18 @@ class MoCoTrainer(_TrainerBase):
             bk = self._buckets
             be = int(getattr(self, 'bucket_elems', BUCKET_ELEMS))
             planning = len(bk) == 1 and not self._planned and 0 < be < self.arena_q.total
+            log = None
             if planning:
-                self._planned = True
-                L.GRAD_LOG = []
-            for i, (_, lo, hi) in enumerate(bk):
-                self._segments[1 + i].run()
-                self._reducer.launch(lo, hi)
+                if L.GRAD_LOG is not None:
+                    raise RuntimeError('another trainer is planning its gradient buckets (engine.layers.GRAD_LOG is live)')
+                L.GRAD_LOG = log = []
+            try:
+                for i, (_, lo, hi) in enumerate(bk):
+                    self._segments[1 + i].run()
+                    self._reducer.launch(lo, hi)
+            finally:
+                if planning:
+                    L.GRAD_LOG = None        # whatever happened in the step, the log never outlives it
             self._reducer.wait()
             self._segments[-1].run()
             if user_ids is None:
@@ -369,8 +388,8 @@ class MoCoTrainer(_TrainerBase):
             if planning:
                 # the first step ran un-staged with the gradient log on: cut the arena into buckets by the closure that
                 # completes each and rebuild the segments, so that every later step overlaps all-reduce and backward
-                log, L.GRAD_LOG = L.GRAD_LOG, None
                 self._buckets = self._buckets_from_log(self.arena_q, log)
+                self._planned = True             # only once the buckets exist: a step that raised is planned again
                 for g in self._segments:
                     g.release()
                 self._segments = None
@@ -384,7 +403,8 @@ class MoCoTrainer(_TrainerBase):
         """Checkpoint dict with the reference's keys (tools/...dis.py:274-286) + the queue pointer."""
         return {'epoch': epoch, 'state_dict': self.model.state_dict(), 'optimizer': self.optimizer.state_dict(),
                 'contrast': self.contrast.state_dict(), 'model_ema': self.model_ema.state_dict(),
-                'queue_index': int(self.contrast.index), 'step_count': int(self.step_count)}
+                'queue_index': int(self.contrast.index), 'step_count': int(self.step_count),
+                **({} if self.scale_state is None else {'loss_scale_state': self.scale_state.detach().cpu().clone()})}
 
     def load_state_dict(self, sd):
         """Resume from state_dict() -- or from a reference checkpoint, which lacks `queue_index` / `step_count`
@@ -396,6 +416,8 @@ class MoCoTrainer(_TrainerBase):
         self.contrast.index = int(sd.get('queue_index', 0)) % self.K
         self.ptr_dev.fill_(self.contrast.index)
         self.step_count = int(sd.get('step_count', 0))
+        if self.scale_state is not None and sd.get('loss_scale_state') is not None:
+            self.scale_state.copy_(sd['loss_scale_state'])
         return int(sd.get('epoch', 0))
 
 
@@ -405,6 +427,8 @@ class SimSiamTrainer(_TrainerBase):
         self.cfg, self.device = cfg, torch.device(device)
         self.clip = clip_value_of(cfg)
         self.ctx = ctx or par.DistCtx()
+        ls = _loss_scale()
+        self.scale_state = None if ls is None else ops.loss_scale_state(ls, torch.device(device))
         if seed is not None:
             torch.manual_seed(seed)
         self.model, ema = create_visual_model(cfg)
@@ -429,13 +453,21 @@ class SimSiamTrainer(_TrainerBase):
         tape = Tape(True)
         lv = self.model.fwd(tape, Var(self._static))
         self.out = dict(loss=lv.t)
-        tape.backward(upto)
+        ops.LOSS_SCALE_STATE[0] = self.scale_state            # fp16 storage: SimSiam.fwd's loss-gradient seed is scaled by S
+        try:
+            tape.backward(upto)
+        finally:
+            ops.LOSS_SCALE_STATE[0] = None
         self._tape = tape if upto > 0 else None
         if upto == 0 and self._packer is not None:
             self._packer.release()
 
     def _bwd_stage(self, upto, last):
-        self._tape.backward(upto)
+        ops.LOSS_SCALE_STATE[0] = self.scale_state
+        try:
+            self._tape.backward(upto)
+        finally:
+            ops.LOSS_SCALE_STATE[0] = None
         if last:
             self._tape = None
             if self._packer is not None:
@@ -445,7 +477,11 @@ class SimSiamTrainer(_TrainerBase):
         if self.ctx.active:
             ops.scale_(self.arena.grad, 1.0 / self.ctx.world)      # DDP's mean (the loss gradient is seeded inside the model)
         clip = None
-        if self.clip is not None:                              # tools/train_video_contrast_dis.py:497-500
+        if self.scale_state is not None:                       # fp16 storage: un-scale + overflow check + clip, see MoCoTrainer
+            clip = ops.grad_unscale_clip(self.arena.grad, self.scale_state, self.clip)
+            self.out['grad_norm'] = clip
+            self.out['loss_scale'] = self.scale_state
+        elif self.clip is not None:                            # tools/train_video_contrast_dis.py:497-500
             clip = self.optimizer.clip_grad_norm(self.clip)
             self.out['grad_norm'] = clip
         self.optimizer.step(grad_clip=clip)
@@ -480,17 +516,23 @@ class SimSiamTrainer(_TrainerBase):
             bk = self._buckets
             be = int(getattr(self, 'bucket_elems', BUCKET_ELEMS))
             planning = len(bk) == 1 and not self._planned and 0 < be < self.arena.total
+            log = None
             if planning:
-                self._planned = True
-                L.GRAD_LOG = []
-            for i, (_, lo, hi) in enumerate(bk):
-                self._segments[i].run()
-                self._reducer.launch(lo, hi)
+                if L.GRAD_LOG is not None:
+                    raise RuntimeError('another trainer is planning its gradient buckets (engine.layers.GRAD_LOG is live)')
+                L.GRAD_LOG = log = []
+            try:
+                for i, (_, lo, hi) in enumerate(bk):
+                    self._segments[i].run()
+                    self._reducer.launch(lo, hi)
+            finally:
+                if planning:
+                    L.GRAD_LOG = None
             self._reducer.wait()
             self._segments[-1].run()
             if planning:
-                log, L.GRAD_LOG = L.GRAD_LOG, None
                 self._buckets = self._buckets_from_log(self.arena, log)
+                self._planned = True
                 for g in self._segments:
                     g.release()
                 self._segments = None

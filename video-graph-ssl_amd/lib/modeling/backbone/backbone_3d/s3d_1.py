@@ -122,6 +122,8 @@ class S3D(nn.Module):
         for m in self.base:                        # incl. graph blocks inserted by lib/ops/build.py
             x = L.f_seq(tape, m, x)
         T, HW = x.t.shape[2], x.t.shape[3] * x.t.shape[4]
+        if isinstance(self.fc, nn.Dropout) and self.fc.p > 0 and self.fc.training:
+            return L.f_s3d_tail_with_dropout(tape, self.fc, x)       # dropout sits between the two averages (:31)
         wt, norm = self._tail_weights(T, HW, x.t.device)
         x = L.f_wavgpool(tape, x, wt, norm)
         if isinstance(self.fc, nn.Sequential):

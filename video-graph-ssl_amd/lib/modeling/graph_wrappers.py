@@ -67,6 +67,10 @@ class SimSiam(nn.Module):
                 if gs != 1.0:
                     ops.scale_(dp1, gs)
                     ops.scale_(dp2, gs)
+            st = ops.LOSS_SCALE_STATE[0]
+            if st is not None:                       # fp16 storage: the loss gradient is seeded x the (device-resident) loss scale
+                ops.scale_dev_(dp1, st)
+                ops.scale_dev_(dp2, st)
             p1.add_grad(dp1)
             p2.add_grad(dp2)
         tape.record(back)

@@ -55,23 +55,50 @@ class GCN(nn.Module):
         return ov
 
 
+class _ConvBN(nn.Sequential):
+    """Sequential(Conv3d, BatchNorm3d): the similarity branch under bn_layer=True (temporal_graph.py:103-113)."""
+
+    def fwd(self, tape, xv):
+        return L.f_conv_bn_act(tape, self[0], self[1], xv, relu=False)
+
+
 class TemporalGraphAug(nn.Module):
+    """Constructor options as in the reference (:66-129).  The shipped configs use the defaults; the others follow the
+    reference's module layout so its state-dict keys load: `sub_sample=False` leaves g_q / g_k as bare convs (keys
+    g_q.weight), `max_pool=False` pools with AvgPool3d((1,2,2)), `bn_layer=True` puts a BatchNorm3d behind each similarity
+    conv (keys g_q.0.0.weight, g_q.0.1.*), `num_gcn_layers > 1` stacks GCN(C->inter), GCN(inter->inter)..., GCN(inter->C)
+    and needs an explicit `inter_channels` (with inter_channels=None the reference passes None as in_features and cannot be
+    built, :95-98).  `mask_frame` raises: the reference's mask indexes the BATCH axis with the frame index (:171-174)."""
+
     def __init__(self, in_channels, inter_channels=None, sub_sample=True, bias=False, bn_layer=False,
                  zero_init=False, max_pool=True, mask_frame=False, nei_size=None, alpah=0.5, num_gcn_layers=1,
                  temperature=1., max_hop=3):
         super().__init__()
-        if bn_layer or mask_frame or not sub_sample or not max_pool or num_gcn_layers != 1:
-            raise NotImplementedError('only the reference defaults (temporal_graph.py:67-70) are on the hot path')
+        if mask_frame:
+            raise NotImplementedError('mask_frame: the reference masks adjacent_matrix[i] by FRAME index i on the batch '
+                                      'axis (temporal_graph.py:171-174); there is no well-defined arithmetic to match')
+        if num_gcn_layers < 1 or (num_gcn_layers > 1 and inter_channels is None):
+            raise ValueError('num_gcn_layers > 1 needs inter_channels (the reference builds GCN(in_features=None) otherwise, '
+                             'temporal_graph.py:95-98)')
         self.in_channels = in_channels
+        self.sub_sample, self.bn_layer, self.max_pool, self.zero_init = sub_sample, bn_layer, max_pool, zero_init
+        self.num_gcn_layers = num_gcn_layers
+        gcn_mid = inter_channels                                # what :95 passes as out_features (None -> C)
         self.inter_channels = max(in_channels // 2, 1) if inter_channels is None else inter_channels
         self.alpha, self.temperature, self.max_hop, self.bias = alpah, temperature, max_hop, bias
-        self.gcns = nn.ModuleList([GCN(in_features=in_channels, out_features=None)])   # C -> C (:95 passes None)
-        pool = HipMaxPool3d(kernel_size=(1, 2, 2))
+        self.gcns = nn.ModuleList([GCN(in_features=in_channels, out_features=gcn_mid)])
+        for i in range(1, num_gcn_layers):
+            self.gcns.append(GCN(in_features=gcn_mid, out_features=in_channels) if i == num_gcn_layers - 1
+                             else GCN(in_features=gcn_mid))
         q = HipConv3d(in_channels, self.inter_channels, 1, 1, 0, bias=bias)
         k = HipConv3d(in_channels, self.inter_channels, 1, 1, 0, bias=bias)
         self.reset_parameters(q, k, zero_init)
-        self.g_q = nn.Sequential(q, pool)
-        self.g_k = nn.Sequential(k, pool)
+        if bn_layer:
+            q, k = _ConvBN(q, L.HipBatchNorm3d(self.inter_channels)), _ConvBN(k, L.HipBatchNorm3d(self.inter_channels))
+        if sub_sample:
+            pool = HipMaxPool3d(kernel_size=(1, 2, 2)) if max_pool else L.HipAvgPool3d(kernel_size=(1, 2, 2))
+            q, k = nn.Sequential(q, pool), nn.Sequential(k, pool)
+        self.g_q, self.g_k = q, k
         self.noise = None          # optional injected uniforms (B,T,T) for deterministic parity tests
 
     def reset_parameters(self, m1, m2, zero_init=False):
@@ -85,11 +112,16 @@ class TemporalGraphAug(nn.Module):
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0) if zero_init else m.bias.data.uniform_(-1. / math.sqrt(n), 1. / math.sqrt(n))
 
+    def _branch(self, tape, mod, xv):
+        if isinstance(mod, HipConv3d):
+            return L.f_conv(tape, mod, xv)
+        return L.f_seq(tape, mod, xv)            # Sequential of conv | _ConvBN, then the pool
+
     def fwd(self, tape, xv):
         x = xv.t
         B, T = x.shape[0], x.shape[2]
-        gq = L.f_maxpool(tape, self.g_q[1], L.f_conv(tape, self.g_q[0], xv))
-        gk = L.f_maxpool(tape, self.g_k[1], L.f_conv(tape, self.g_k[0], xv))
+        gq = self._branch(tape, self.g_q, xv)
+        gk = self._branch(tape, self.g_k, xv)
         u = self.noise
         if u is None:
             u = torch.rand((B, T, T), device=x.device)        # RelaxedBernoulli.rsample's uniforms

@@ -43,8 +43,9 @@ class HipSGD(object):
         ops.fill(self.arena.grad, 0.0)
 
     def step(self, grad_clip=None):
-        """grad_clip: optional device (norm, coef) pair from clip_grad_norm(): the coefficient is applied to every
-        gradient inside the update kernel."""
+        """grad_clip: optional device (norm, coef, skip, -) record from clip_grad_norm() / ops.grad_unscale_clip(): the
+        coefficient is applied to every gradient inside the update kernel; a set skip flag (non-finite gradient under
+        loss scaling) leaves parameters and momentum untouched."""
         self._sync_tables()
         ops.sgd_step(self.arena.flat, self.arena.grad, self.buf, self.chunk_lr, self.chunk_wd, 1.0,
                      self.momentum, self.nesterov, grad_clip)
