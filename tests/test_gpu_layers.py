@@ -153,13 +153,18 @@ def test_configs1_every_layer_fwd_dgrad_wgrad_under_tuned_shapes(pkg, tuned_laun
 
 # ------------------------------------------------------------------------------------------------ configs[3], graph sites
 @pytest.mark.parametrize('C,T,HW', [(192, 8, 28), (512, 4, 14), (832, 2, 7)])
-@pytest.mark.parametrize('math', ['bf16x6', 'f32'])
-def test_configs3_graph_block_at_224_sites_vs_fp64_oracle(pkg, math, C, T, HW):
+@pytest.mark.parametrize('math,xscale', [('bf16x6', 0.1), ('f32', 0.1), ('bf16x6', 1.0), ('f32', 1.0)])
+def test_configs3_graph_block_at_224_sites_vs_fp64_oracle(pkg, math, xscale, C, T, HW):
     """TemporalGraphAug as configs[3] runs it (S3D at 224 x 224 crops, 4 clips: before Mixed_3b / Mixed_4c / Mixed_5b):
     block forward and backward through the product module against the oracle block in fp64, RelaxedBernoulli noise
     injected, plus each piece on its own -- the three 1x1x1 convolutions (forward, dgrad, wgrad), the Gram / softmax /
-    hop-weight / sample chain and the message passing.  The block is smooth (no ReLU, no BatchNorm; the one max-pool sits
-    on random data without ties), so the bar is 2e-5 on everything."""
+    hop-weight / sample chain and the message passing.  The block has no ReLU and no BatchNorm, but its softmax sits on Gram
+    logits that are sums of C/2 x H/2 x W/2 (18816 at the first site) products of max-pooled -- hence positive-mean -- maps:
+    a common offset of ~70 (activations scaled by 0.1) to ~7000 (unit variance, what BatchNorm feeds the block in the
+    model), and a softmax turns the ABSOLUTE rounding error of such a sum into a relative error of its output.  That is a
+    property of fp32, not of a kernel: the yardstick for everything downstream of the softmax is therefore the fp32 CPU
+    oracle's own distance from fp64 on the same data (bar = 4 x that, floor 2e-5; measured here 2e-5..9e-5 for both).  The
+    pieces that do not pass through the softmax (the convolutions, the message passing) keep 1e-5."""
     from oracle import graph as ograph
     ops = pkg.engine.ops
     default = ops.get_conv_math()
@@ -168,12 +173,21 @@ def test_configs3_graph_block_at_224_sites_vs_fp64_oracle(pkg, math, C, T, HW):
         torch.manual_seed(100 + C)
         ref = ograph.TemporalGraphAug(C).double()
         B = 4
-        x = torch.randn(B, C, T, HW, HW)
+        x = torch.randn(B, C, T, HW, HW) * xscale
         u = torch.rand(B, T, T)
         dout = torch.randn(B, C, T, HW, HW)
         xr = x.double().requires_grad_(True)
         yr = ref(xr, u=u.double())
         yr.backward(dout.double())
+        # the fp32 CPU oracle on the same data: how far fp32 lands from fp64 through this softmax
+        ref32 = ograph.TemporalGraphAug(C)
+        ref32.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+        x32 = x.clone().requires_grad_(True)
+        y32 = ref32(x32, u=u)
+        y32.backward(dout)
+        e32 = max([rel_err(y32, yr), rel_err(x32.grad, xr.grad)] +
+                  [rel_err(p32.grad, pr.grad) for p32, pr in zip(ref32.parameters(), ref.parameters())])
+        bar = max(2e-5, 4 * e32)
         # ---- the product module, reference-shaped API
         tg = pkg.lib.ops.module_wrappers.temporal_graph
         aug = tg.TemporalGraphAug(C)
@@ -186,10 +200,10 @@ def test_configs3_graph_block_at_224_sites_vs_fp64_oracle(pkg, math, C, T, HW):
         yv = aug.fwd(tape, xv)
         yv.grad = dout.to(DEV)
         tape.backward()
-        assert rel_err(yv.t, yr) < 2e-5
-        assert rel_err(xv.grad, xr.grad) < 2e-5
+        assert rel_err(yv.t, yr) < bar
+        assert rel_err(xv.grad, xr.grad) < bar
         for (n, p), (_, pr) in zip(aug.named_parameters(), ref.named_parameters()):
-            assert rel_err(p.grad, pr.grad) < 2e-5, n
+            assert rel_err(p.grad, pr.grad) < bar, n
         # ---- the pieces, through the op wrappers
         wq, wk, wg = (ref.state_dict()[n] for n in ('g_q.0.weight', 'g_k.0.weight', 'gcns.0.conv.weight'))
         xq = x.to(DEV)
@@ -216,9 +230,9 @@ def test_configs3_graph_block_at_224_sites_vs_fp64_oracle(pkg, math, C, T, HW):
         adj_r.backward(dadj.double())
         gqd, gkd = gq.float().to(DEV).contiguous(), gk.float().to(DEV).contiguous()
         sim, pre, adj = ops.graph_adj_fwd(gqd, gkd, u.to(DEV), 3, 0.5, 1.0)
-        assert rel_err(sim, sim_r) < 2e-5 and rel_err(pre, pre_r) < 2e-5 and rel_err(adj, adj_r) < 2e-5
+        assert rel_err(sim, sim_r) < bar and rel_err(pre, pre_r) < bar and rel_err(adj, adj_r) < bar
         dgq, dgk = ops.graph_adj_bwd(dadj.to(DEV), gqd, gkd, sim, pre, adj, 3, 0.5, 1.0)
-        assert rel_err(dgq, gqr.grad) < 2e-5 and rel_err(dgk, gkr.grad) < 2e-5
+        assert rel_err(dgq, gqr.grad) < bar and rel_err(dgk, gkr.grad) < bar
         # message passing (einsum + skip) and its two gradients
         s = torch.randn(B, C, T, HW, HW)
         sr, ar = s.double().requires_grad_(True), adj_r.detach().clone().requires_grad_(True)
@@ -229,6 +243,7 @@ def test_configs3_graph_block_at_224_sites_vs_fp64_oracle(pkg, math, C, T, HW):
         assert rel_err(out, outr) < 1e-5
         ds, da = ops.graph_gcn_bwd(adjd, s.to(DEV), dout.to(DEV))
         assert rel_err(ds, sr.grad) < 1e-5 and rel_err(da, ar.grad) < 2e-5
+        print('graph site C=%d T=%d %s x%.1f: fp32 CPU oracle vs fp64 %.1e -> bar %.1e' % (C, T, math, xscale, e32, bar))
     finally:
         ops.set_conv_math(default)
 

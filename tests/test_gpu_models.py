@@ -456,9 +456,12 @@ def test_temporal_graph_block_constructor_options_golden(pkg, golden, tag, kw):
     assert rel_err(y, g.t(tag + ':y')) < 1e-4
     assert rel_err(dx, g.t(tag + ':dx')) < 1e-3
     grads = g.group(tag + ':g:')
+    gmax = max(float(v.abs().max()) for v in grads.values())
     for n, p in aug.named_parameters():
-        scale = max(float(grads[n].abs().max()), 1e-6)
-        assert float((p.grad.cpu() - grads[n]).abs().max()) < 1e-3 * scale + 1e-7, n
+        # (a bias / BatchNorm shift of g_k moves every logit of a softmax row by the same amount: its true gradient is exactly
+        # zero and both sides hold rounding noise ~1e-5 -- hence the floor relative to the block's largest gradient)
+        scale = max(float(grads[n].abs().max()), 1e-2 * gmax)
+        assert float((p.grad.cpu() - grads[n]).abs().max()) < 1e-3 * scale, (n, gmax)
     if tag == 'bn':
         after = g.group(tag + ':after:')
         for k_, v in aug.state_dict().items():
@@ -535,7 +538,9 @@ def test_dropout_branch_of_prepare_video_model(pkg, backbone, T):
     assert rel_err(q, qr) < 1e-3
     gr = dict(ref.named_parameters())
     errs = [parity.rel(p.grad, gr[n].grad) for n, p in model.named_parameters() if float(gr[n].grad.abs().max()) > 0]
-    assert sorted(errs)[len(errs) // 2] < 1e-3
+    # S3D's 77 BatchNorms over 4 small clips + 13 max pools make its fp32 gradients chaotic for any implementation (the fp32
+    # CPU oracle itself sits 4e-2..1e-1 from fp64: tests/test_gpu_configs.py); a wrong factor in the dropout tail would be O(1)
+    assert sorted(errs)[len(errs) // 2] < (1e-3 if backbone != 'S3D' else 5e-2)
     # eval mode: dropout is the identity
     model.eval()
     ref.eval()

@@ -13,6 +13,7 @@ raises if it has not been built -- there is no CPU fallback.
 from . import _hip  # noqa: F401  (fails loudly when the HIP library is missing)
 from . import engine, lib, parallel  # noqa: F401
 from .engine.trainer import MoCoTrainer, SimSiamTrainer  # noqa: F401
+from .lib import evaluation  # noqa: F401  (accuracy / AverageMeter, lib/evaluation/metric.py)
 from .lib.config import CfgNode, get_defaults  # noqa: F401
 from .lib.memory import create_contrast, create_criterion  # noqa: F401
 from .lib.modeling import create_visual_model  # noqa: F401
