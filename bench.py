@@ -3,7 +3,7 @@
 N MI355X of one node + InfoNCE forward ms, with the dominant kernel's roofline fraction and the CPU
 oracle timed beside it.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -66,8 +66,8 @@ T_START = time.time()
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=0, help='clips per GPU (default 32; 16 with --math fp16)')
     ap.add_argument('--frames', type=int, default=0, help='default 16 (32 with --math fp16)')
     ap.add_argument('--size', type=int, default=0, help='default 112 (224 with --math fp16)')
@@ -83,6 +83,8 @@ def parse():
                          "fp32 master weights / statistics / head -- an HBM-bound workload, reported against the HBM roofline")
     ap.add_argument('--no-other-math', action='store_true', help='skip timing the other arithmetic modes')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sub-workloads', action='store_true',
+                    help='skip the configs[3] (simsiam), configs[4] (fp16) and input-stage sub-records of the default N=1 run')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--layer-table', action='store_true', help='log per-layer conv kernel timings to stderr')
     ap.add_argument('--workload', default='moco', choices=['moco', 'simsiam'],
@@ -234,7 +236,11 @@ def kernel_timing(pkg, trainer, args):
 
     def roof_of(dom):
         ach = table[dom]['tflops']
-        common = dict(kernel=dom, traffic=pmc_traffic(dom), avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4),
+        tr_ = pmc_traffic(dom)
+        common = dict(kernel=dom, traffic=tr_,
+                      traffic_source=None if tr_ is None else 'profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload '
+                                     '(tools/pmc_step.sh), committed -- not re-measured in this run' % PMC_FILE[_MATH[0] == 3],
+                      avg_launch_ms=round(sym[dom][0] / sym[dom][2], 4),
                       launches_per_step=sym[dom][2], flops_per_launch_avg=round(sym[dom][1] / sym[dom][2], 1),
                       algorithmic_bytes_per_launch_avg=round(sym[dom][3] / sym[dom][2], 1))
         if _MATH[0] == 0:
@@ -274,13 +280,15 @@ def step_bytes_roofline(table, step_s):
                 GBps=round(gb / step_s, 1), hbm_frac=round(gb / step_s / PEAK_HBM_GBPS, 4))
 
 
+PMC_FILE = {False: 'pmc_traffic.json', True: 'pmc_traffic_f16.json'}
+
+
 def pmc_traffic(symbol):
     """HBM bytes per launch of `symbol` from the committed rocprofv3 PMC passes of this same workload
     (profiles/pmc_traffic.json, produced by tools/pmc_step.sh + tools/pmc_parse.py: separate FETCH_SIZE and
     WRITE_SIZE passes; gfx950 correction 2x FETCH_SIZE, calibrated in that file on the EMA/SGD kernels).
     None when the profile has no entry for this kernel (different launch configuration than profiled)."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles',
-                        'pmc_traffic_f16.json' if _MATH[0] == 3 else 'pmc_traffic.json')     # (the fp16-storage step has its own passes)
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', PMC_FILE[_MATH[0] == 3])     # (the fp16-storage step has its own passes)
     try:
         with open(path) as f:
             prof = json.load(f)['kernels']
@@ -390,8 +398,10 @@ def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = float(out['loss'].item())
+    tr.close()
+    del tr
     if rank != 0:
-        return
+        return None
     gt = graph_timing(pkg, bsz, 192, 8, size // 8)
     res = {'metric': 'pretrain_clips_per_sec', 'value': round(bsz * world * args.steps / dt, 3), 'unit': 'clips/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -405,7 +415,101 @@ def simsiam_main(args, pkg, dev, ctx, world, rank, barrier):
                             peak=PEAK_HBM_GBPS, unit='GB/s', frac=gt['hbm_frac'], traffic=pmc_hbm('tmix_kernel<8>') if (bsz, size) == (4, 224) else None, avg_launch_ms=gt['ms'],
                             algorithmic_MB=gt['algorithmic_MB']),
            'graph_mix_fwd': gt}
-    emit(res)
+    return res
+
+
+def fp16_subrecord(pkg, dev, ctx, args):
+    """BASELINE configs[4] at N = 1 inside the default run: 3D-ResNet-50, 32 x 224 x 224, 16 clips, fp16 storage."""
+    import argparse
+    import gc
+    a = argparse.Namespace(**vars(args))
+    a.math = 'fp16'
+    for k, v in FP16_DEFAULTS.items():
+        setattr(a, k, v)
+    ops = pkg.engine.ops
+    ops.set_conv_math('fp16')
+    saved = _MATH[0]
+    _MATH[0] = 3
+    try:
+        K = 4096
+        tr = pkg.MoCoTrainer(make_cfg(pkg, a, K), dev, ctx=ctx, use_graph=not a.no_graph, seed=1)
+        torch.manual_seed(1)
+        images = torch.randn(a.batch, 6, a.frames, a.size, a.size, device=dev)
+        for _ in range(max(a.warmup, 0) + 3):
+            out = tr.train_step(images)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = tr.train_step(images)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rec = {'value': round(a.batch * a.steps / dt, 3), 'unit': 'clips/s', 'dtype': DTYPE['fp16'], 'steps': a.steps,
+               'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3), 'final_loss': round(float(out['loss'].item()), 5),
+               'loss_scale': float(out['loss_scale'][0]), 'skipped_steps': int(out['loss_scale'][2]),
+               'config': {'workload': 'MoCo pre-training iteration, %s, %d-frame %dx%d clips, %d clips/GPU, queue K=%d, fp16 storage '
+                                      '(BASELINE.json configs[4] at N=1)' % (a.backbone, a.frames, a.size, a.size, a.batch, K)}}
+        if not a.no_kernel_timing:
+            rec['roofline'], kernels = kernel_timing(pkg, tr, a)
+            rec['roofline_step'] = step_bytes_roofline(kernels, dt / a.steps)
+        tr.close()
+        del tr, images
+        gc.collect()
+        torch.cuda.empty_cache()
+        return rec
+    finally:
+        ops.set_conv_math(args.math)
+        _MATH[0] = saved
+
+
+def simsiam_subrecord(pkg, dev, ctx, args):
+    """BASELINE configs[3] inside the default run: S3D + graph blocks + SimSiam, 16 x 224 x 224, 4 clips."""
+    import argparse
+    import gc
+    a = argparse.Namespace(**vars(args))
+    a.workload, a.backbone, a.frames, a.size, a.batch = 'simsiam', 'S3D', 16, 224, 4
+    rec = simsiam_main(a, pkg, dev, ctx, 1, 0, torch.cuda.synchronize)
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {k: rec[k] for k in ('value', 'unit', 'dtype', 'steps', 'warmup', 'ms_per_step', 'final_loss', 'config',
+                                'step_tflops_algorithmic', 'roofline')}
+
+
+def input_stage_subrecord(pkg, dev, tr, args, base_ms):
+    """The same iteration fed through the device-side input stage (engine.input): every step stages a uint8 batch
+    (b, 2, T, 128, 171, 3) from pinned host memory on the copy stream while the previous step runs, and gca_clip_prepare
+    (crop + flip + normalise + layout) writes the trainer's static batch.  PCIe-inclusive; never the headline value."""
+    import numpy as np
+    inp = pkg.engine.input
+    Hs, Ws = max(128, args.size), max(171, args.size)
+    stage = inp.DeviceInputStage(args.batch, args.frames, (Hs, Ws), args.size, dev)
+    rng = np.random.RandomState(0)
+    frames = torch.from_numpy(rng.randint(0, 256, size=(args.batch, 2, args.frames, Hs, Ws, 3)).astype(np.uint8)).pin_memory()
+    params = np.zeros((args.batch, 2, 4), dtype=np.int32)
+    params[..., 0] = rng.randint(0, Hs - args.size + 1, size=(args.batch, 2))
+    params[..., 1] = rng.randint(0, Ws - args.size + 1, size=(args.batch, 2))
+    params[..., 2] = rng.randint(0, 2, size=(args.batch, 2))
+    nxt = stage.stage(frames, params)
+    for _ in range(3):
+        cur, nxt = nxt, stage.stage(frames, params)
+        tr.train_step(cur)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cur, nxt = nxt, stage.stage(frames, params)
+        tr.train_step(cur)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # the kernel alone, on buffers that are not cache resident (the uint8 batch is 4x smaller than the fp32 one it replaces)
+    out = torch.empty(stage.out_shape(), device=dev)
+    fd, pd = frames.to(dev), torch.from_numpy(params).to(dev)
+    ms = ev_time_ms(lambda: inp.clip_prepare(fd, pd, stage.mean255, stage.inv_std255, args.size, args.size, out=out), 10, 2)
+    px = args.batch * 2 * args.frames * args.size * args.size
+    return {'value': round(args.batch * args.steps / dt, 3), 'unit': 'clips/s', 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'ms_per_step_resident_fp32': round(base_ms, 3), 'h2d_MB_per_step': round(stage.frame_bytes / 1e6, 1),
+            'fp32_batch_MB_it_replaces': round(px * 3 * 4 / 1e6, 1), 'source_frames': [Hs, Ws],
+            'clip_prepare': {'ms': round(ms, 4), 'algorithmic_MB': round(px * 15 / 1e6, 1),
+                             'GBps': round(px * 15 / 1e9 / (ms / 1e3), 1), 'hbm_frac': round(px * 15 / 1e9 / (ms / 1e3) / PEAK_HBM_GBPS, 4)},
+            'note': 'uint8 frames from pinned host memory every step (double-buffered copy stream) + gca_clip_prepare; PCIe-inclusive'}
 
 
 def host_cores():
@@ -521,7 +625,10 @@ def main():
     pkg.engine.ops.set_conv_math(args.math)
     _MATH[0] = 3 if args.math == 'fp16' else pkg.engine.ops.CONV_MATH[args.math]
     if args.workload == 'simsiam':
-        return simsiam_main(args, pkg, dev, ctx, world, rank, barrier)
+        res = simsiam_main(args, pkg, dev, ctx, world, rank, barrier)
+        if res is not None:
+            emit(res)
+        return
     K = args.queue or (4096 if world == 1 else 65536)
     cfg = make_cfg(pkg, args, K)
     tr = pkg.MoCoTrainer(cfg, dev, ctx=ctx, use_graph=not args.no_graph, seed=1)
@@ -583,8 +690,14 @@ def main():
     if not args.no_kernel_timing:
         res['roofline'], res['kernels'] = kernel_timing(pkg, tr, args)
         log('kernel timing done')
+    default_workload = (args.backbone, args.frames, args.size, args.batch, args.math) == ('R2P1D18', 16, 112, 32, 'bf16x6')
+    subs = world == 1 and default_workload and not args.no_sub_workloads and not dist_shape
+    if subs:
+        res['input_stage'] = input_stage_subrecord(pkg, dev, tr, args, dt / args.steps * 1e3)
+        log('input stage timed')
     if world == 1 and not args.no_other_math and args.math != 'fp16':
         # the same workload in the other arithmetic modes (own trainer, own tuned plans), timed the same way
+        tr.close()
         del tr
         import gc
         for other in [m for m in ('f32', 'bf16x6', 'bf16x3') if m != args.math]:
@@ -612,6 +725,15 @@ def main():
         _MATH[0] = pkg.engine.ops.CONV_MATH[args.math]
     if args.math == 'fp16' and not args.no_kernel_timing:
         res['roofline_step'] = step_bytes_roofline(res['kernels'], dt / args.steps)
+    if subs:
+        import gc
+        tr = None
+        gc.collect()
+        torch.cuda.empty_cache()
+        res['simsiam'] = simsiam_subrecord(pkg, dev, ctx, args)       # BASELINE configs[3]
+        log('configs[3] (simsiam) timed')
+        res['fp16'] = fp16_subrecord(pkg, dev, ctx, args)              # BASELINE configs[4] at N = 1
+        log('configs[4] (fp16 storage) timed')
     if world == 1:
         if not args.no_cpu_baseline:
             res['cpu_baseline'] = cpu_baseline(args, K)

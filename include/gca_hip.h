@@ -316,6 +316,25 @@ int gca_graph_gcn_bwd(const float* adj, const float* s, const float* dout, int64
                       int64_t HW, float* ds, float* dadj, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Device-side tail of the input pipeline.  Replaces, for uint8 frames already decoded / resized on the
+ * host, the last stages of the reference's transform chain and its collation:
+ *   VideoRandomHorizontalFlip + VideoNormalize + VideoToTensor  (lib/data/transform/consistency_transforms.py:11-65,
+ *   composed in lib/data/transform/build.py:45-62), an integer crop window (albumentations random_crop coordinates as
+ *   VideoRandomCrop / VideoCenterCrop use them), the channel concatenation of the two views
+ *   (lib/data/datasets/video_contrast_dataset.py:196-203) and the H2D copy of the fp32 batch (tools/...dis.py:402).
+ *   frames : (b, views, T, Hs, Ws, 3) uint8, HWC frames as cv2 delivers them (device memory)
+ *   params : (b, views, 4) int32 on the device: {h0, w0, flip, 0} -- ONE crop origin and flip decision per (clip, view), shared
+ *            by its T frames (the reference's transforms draw them once per clip); windows are clamped into the frame
+ *   mean255, inv_std255 : HOST pointers to 3 floats each: f32(mean_c)*255 and 1/(f32(std_c)*255), computed in fp32 as numpy
+ *            does in VideoNormalize.normalize (:53-65)
+ *   out    : (b, 3*views, T, H, W) fp32, or fp16 when out_f16 (the fp16-storage path): out = (float(px) - m_c) * d_c,
+ *            two fp32 roundings -- bit-identical to the reference's arithmetic
+ * One pass over HBM, 3 B read + 12 (6) B written per pixel. */
+int gca_clip_prepare(const uint8_t* frames, int64_t b, int64_t views, int64_t T, int64_t Hs, int64_t Ws,
+                     const int32_t* params, const float* mean255, const float* inv_std255, int64_t H, int64_t W,
+                     void* out, int out_f16, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Multi-tensor parameter updates over flat, 256-element-aligned parameter arenas.
  * _momentum_update (tools/train_video_contrast_dis.py:177-180) and torch.optim.SGD as
  * configured by make_optimizer (lib/solver/build.py:24-59: one group per parameter).

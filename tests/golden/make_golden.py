@@ -13,6 +13,10 @@ Harness shims applied at import time (reference files unto
   3. register the unexported backbones on the imported backbone_3d package
   4. cfg objects are types.SimpleNamespace (yacs absent)
   5. collections.Iterable = collections.abc.Iterable  (lr_scheduler.py:54 on Python >= 3.10)
+  6. (gen_input only) inert placeholder modules for `cv2` and `albumentations.augmentations.functional`, which
+     lib/data/transform/consistency_transforms.py imports at its top and which are not installed: any attribute reads as 0
+     (the file uses cv2.INTER_LINEAR etc. as default arguments), nothing of them is ever CALLED -- the two classes exercised,
+     VideoNormalize and VideoToTensor, are pure numpy / torch
 """
 import collections
 import collections.abc
@@ -355,6 +359,39 @@ def gen_graph_options():
     npz('graph_options', **out)
 
 
+def gen_input():
+    """VideoNormalize + VideoToTensor of the reference on random uint8 frames (consistency_transforms.py:11-65)."""
+    import importlib.util
+    import types
+
+    class _Inert(types.ModuleType):                               # shim 6
+        def __getattr__(self, name):
+            if name.startswith('__'):
+                raise AttributeError(name)
+            return 0
+    for name in ('cv2', 'albumentations', 'albumentations.augmentations', 'albumentations.augmentations.functional'):
+        sys.modules.setdefault(name, _Inert(name))
+        if '.' in name:                                           # `import a.b.c as F` walks the attributes
+            parent, leaf = name.rsplit('.', 1)
+            setattr(sys.modules[parent], leaf, sys.modules[name])
+    spec_ = importlib.util.spec_from_file_location('ref_consistency_transforms',
+                                                   os.path.join(REF, 'lib', 'data', 'transform', 'consistency_transforms.py'))
+    ct = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(ct)
+    rng = np.random.RandomState(7)
+    out = {}
+    for tag, (T, H, W), mean, std in (('a', (4, 9, 11), (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)),
+                                      ('b', (3, 8, 8), (0.5, 0.45, 0.4), (0.25, 0.3, 0.2))):
+        frames = [rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8) for _ in range(T)]
+        frames[0][0, 0] = (0, 255, 128)                            # the extremes are in
+        norm = ct.VideoNormalize(mean=mean, std=std)(frames)
+        ten = ct.VideoToTensor(backbone_type='3D')(norm)
+        assert ten.dtype == torch.float32 and tuple(ten.shape) == (3, T, H, W)
+        out.update({tag + ':frames': np.stack(frames), tag + ':mean': np.array(mean), tag + ':std': np.array(std),
+                    tag + ':norm0': norm[0], tag + ':tensor': ten})
+    npz('input', **out)
+
+
 # ------------------------------------------------------------------ 6. SimSiam / step traces / solver
 def gen_steps():
     out = {}
@@ -436,6 +473,6 @@ def gen_steps():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['ops', 'blocks', 'models', 'moco', 'graph', 'steps']
+    which = sys.argv[1:] or ['ops', 'blocks', 'models', 'moco', 'graph', 'graph_options', 'input', 'steps']
     for w in which:
         globals()['gen_' + w]()

@@ -229,3 +229,25 @@ def test_lr_schedule(golden):
     want = g.z['lr:weights_epoch0_199']
     got = [0.06 * omoco.warmup_multistep_factor(e) for e in range(200)]
     assert np.allclose(got, want, rtol=1e-6)
+
+
+def test_input_stage_normalize_and_to_tensor(golden):
+    """oracle.input against the reference's VideoNormalize / VideoToTensor (consistency_transforms.py:11-65): bit for bit --
+    both are the same fp32 numpy statements."""
+    from oracle import input as oinput
+    g = golden('input')
+    for tag in ('a', 'b'):
+        frames = g.z[tag + ':frames']
+        mean, std = tuple(g.z[tag + ':mean']), tuple(g.z[tag + ':std'])
+        n0 = oinput.video_normalize(frames[0], mean, std)
+        assert n0.dtype == np.float32 and np.array_equal(n0, g.z[tag + ':norm0'])
+        ten = oinput.video_to_tensor([oinput.video_normalize(f, mean, std) for f in frames])
+        assert torch.equal(ten, g.t(tag + ':tensor'))
+        # the composed sample builder with an identity crop / no flip is the same thing, twice, on the channel axis
+        T, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        s = oinput.make_sample(np.stack([frames, frames]), [(0, 0, 0), (0, 0, 0)], H, W, mean, std)
+        assert tuple(s.shape) == (6, T, H, W) and torch.equal(s[:3], ten) and torch.equal(s[3:], ten)
+    # index maps restated from albumentations / cv2 (third party, not in the reference tree): self-consistency only
+    img = np.arange(2 * 5 * 3, dtype=np.uint8).reshape(2, 5, 3)
+    assert np.array_equal(oinput.hflip(img)[:, 0], img[:, 4]) and np.array_equal(oinput.hflip(oinput.hflip(img)), img)
+    assert oinput.random_crop_coords(10, 20, 4, 8, 0.0, 0.999) == (0, 11) and oinput.random_crop_coords(10, 20, 4, 8, 0.5, 0.5) == (3, 6)

@@ -103,6 +103,7 @@ SIGNATURES = {
     'gca_sgd_step': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp]),
     'gca_grad_clip_ws_bytes': (c_i64, []),
     'gca_grad_clip_coef': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    'gca_clip_prepare': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
     'gca_rank_ge': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'gca_grad_unscale_clip': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     'gca_scale_dev': (c_i32, [c_vp, c_i64, c_vp, c_f32, c_vp]),

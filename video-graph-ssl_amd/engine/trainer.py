@@ -22,6 +22,7 @@ import torch
 from . import layers as L
 from . import ops
 from .arena import arena_of
+from .input import StagedBatch
 from .layers import BatchedPacker
 from .tape import Tape, Var
 from .. import parallel as par
@@ -105,6 +106,13 @@ def _check_unsupported(cfg):
 FORK_KEY_ENCODER = os.environ.get('GCA_FORK_KEY', '1') != '0'
 # gradient all-reduce bucket: 8 M fp32 = 32 MB (four buckets for R(2+1)D-18 + head); 0 = one all-reduce after the backward pass
 BUCKET_ELEMS = int(os.environ.get('GCA_BUCKET_ELEMS', 8 << 20))
+
+
+class _ShapeOnly(object):
+    """Stand-in for the fp32 batch a StagedBatch will become (shape / device bookkeeping of _ensure_static)."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device, self.dtype = torch.Size(shape), device, torch.float32
 
 
 class _TrainerBase(object):
@@ -198,8 +206,8 @@ class MoCoTrainer(_TrainerBase):
             W = self.ctx.world
             D = int(self.cfg.CROSS.FEAT_DIM)
             self._static = dict(
-                images=torch.empty_like(images),
-                key_in=torch.empty((b,) + (3,) + tuple(images.shape[2:]), dtype=images.dtype, device=self.device)
+                images=torch.empty(tuple(images.shape), dtype=torch.float32, device=self.device),
+                key_in=torch.empty((b,) + (3,) + tuple(images.shape[2:]), dtype=torch.float32, device=self.device)
                 if self.ctx.active else None,
                 k_shuf=torch.empty((b, D), dtype=torch.float32, device=self.device),
                 k=torch.empty((b, D), dtype=torch.float32, device=self.device),
@@ -323,16 +331,24 @@ class MoCoTrainer(_TrainerBase):
 
     # -------------------------------------------------------------------------------- step
     def train_step(self, images, shuffle_ids=None):
-        """images: (b, 6, T, H, W) fp32 on the device.  Returns dict(loss, logits, rank, q) of device
-        tensors (no host sync).  shuffle_ids: optional host int64 permutation of the node batch."""
-        if images.device != self.device or images.dtype != torch.float32:
-            raise RuntimeError('train_step needs fp32 clips already resident on %s' % self.device)
+        """images: (b, 6, T, H, W) fp32 on the device, or a StagedBatch of engine.input.DeviceInputStage (uint8 frames on
+        their way to the device: the crop / flip / normalise / layout pass then writes the static batch directly).
+        Returns dict(loss, logits, rank, q) of device tensors (no host sync).  shuffle_ids: optional host int64 permutation
+        of the node batch."""
+        staged = images if isinstance(images, StagedBatch) else None
+        if staged is not None:
+            images = _ShapeOnly(staged.stage.out_shape(), self.device)
+        elif images.device != self.device or images.dtype != torch.float32:
+            raise RuntimeError('train_step needs fp32 clips already resident on %s (or a StagedBatch)' % self.device)
         s = self._ensure_static(images)
         b, W = images.shape[0], self.ctx.world
         user_ids = shuffle_ids
         if shuffle_ids is None and not self.ctx.active:
             shuffle_ids = par.shared_permutation(b * W, self.perm_seed, self.step_count)
-        s['images'].copy_(images)
+        if staged is not None:
+            staged.stage.prepare(staged, s['images'])
+        else:
+            s['images'].copy_(images)
         self.optimizer._sync_tables()
         if not self.ctx.active:
             s['enq_idx'].copy_(shuffle_ids)
@@ -487,11 +503,17 @@ class SimSiamTrainer(_TrainerBase):
         self.optimizer.step(grad_clip=clip)
 
     def train_step(self, images):
-        if self._static is None or self._static.shape != images.shape:
-            self._static = torch.empty_like(images)
+        """images: (b, 6, T, H, W) fp32 on the device, or a StagedBatch (engine.input.DeviceInputStage)."""
+        staged = images if isinstance(images, StagedBatch) else None
+        shape = torch.Size(staged.stage.out_shape()) if staged is not None else images.shape
+        if self._static is None or self._static.shape != shape:
+            self._static = torch.empty(tuple(shape), dtype=torch.float32, device=self.device)
             self._packer = None
             self._segments = None
-        self._static.copy_(images)
+        if staged is not None:
+            staged.stage.prepare(staged, self._static)
+        else:
+            self._static.copy_(images)
         self.optimizer._sync_tables()
         if not self.ctx.active:
             if self._segments is None:
