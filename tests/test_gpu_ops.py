@@ -844,3 +844,62 @@ def test_bn_train_fwd_and_small_bwd_equal_the_separate_passes(ops, N, C, SP, res
         dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
         dx2 = ops.bn_bwd(dz, None, x, gam, mean, invstd, 2, N, C, SP, dg2, db2, None, False, scale, shift)
         assert torch.equal(dx2, dx) and torch.equal(dg2, dg)
+
+
+@pytest.mark.parametrize('shape,K,kd,pd', [
+    ((2, 40, 9, 4, 8), 48, 7, 3),       # stem-temporal kind: C, K not multiples of 32 (tile tails), D > kd, HW = 32
+    ((3, 33, 5, 4, 4), 70, 7, 3),       # D < kd: most taps of most planes lie in the padding; HW = 16; odd unit count
+    ((2, 64, 1, 4, 4), 32, 7, 3),       # D = 1: only the centre tap ever meets data
+    ((2, 50, 8, 4, 12), 64, 3, 1),      # residual-block kind, HW = 48
+    ((5, 70, 4, 8, 8), 96, 3, 1),
+    ((2, 32, 6, 4, 4), 40, 3, 0),       # "valid" temporal conv: OD = D - 2
+    ((2, 32, 3, 4, 4), 40, 3, 2),       # over-padded: OD = D + 2
+])
+def test_conv_wgrad_streaming_temporal_kernel(ops, shape, K, kd, pd):
+    """conv3d_wgrad_ts.hip (tune_wgrad_tile 11 / 12: the register-window weight gradient of (kd,1,1) unit-stride convs) forced
+    over both wave tiles, split counts from one workgroup to one unit per wave, both split-product arithmetics, += into a
+    live buffer and a batch-strided x view -- against ATen's weight gradient in fp64.  fp32-MFMA mode must refuse it."""
+    torch.manual_seed(kd * 100 + shape[1])
+    N, C, D, Hh, W = shape
+    big = torch.randn(N, 2 * C, D, Hh, W)
+    x = big[:, C:]                                           # batch-strided view (the second view of a clip pair)
+    w = torch.randn(K, C, kd, 1, 1) * 0.1
+    xr, wr = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, 1, (pd, 0, 0))
+    dy = torch.randn(yr.shape)
+    yr.backward(dy.double())
+    units = N * (Hh * W // 16)
+    default = ops.get_conv_math()
+    bigd, dyd = big.to(DEV), dy.to(DEV)
+    xd = bigd[:, C:]
+    try:
+        for mode, tol in (('bf16x6', 1e-5), ('bf16x3', 5e-5)):
+            ops.set_conv_math(mode)
+            for view in (False, True):
+                xin = xd if view else xd.contiguous()
+                plan = ops.ConvPlan(N, C, D, Hh, W, K, (kd, 1, 1), 1, (pd, 0, 0), DEV, x_batch_stride=xin.stride(0) if view else 0)
+                plan.tuned = [True, True, True]
+                for tile in (11, 12):
+                    if tile == 12 and kd == 7:
+                        continue
+                    for sp in sorted({1, 2, max(1, units // 8), max(1, units // 4)}):
+                        plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = tile, sp
+                        plan.refresh()
+                        cfg = plan.cfg(2)
+                        assert cfg[3] & 255 == tile, (tile, cfg)                       # really the streaming kernel
+                        dw = torch.full_like(w, 0.5).to(DEV)
+                        ops.conv_wgrad(plan, xin, dyd, dw, accumulate=True)
+                        assert rel_err(dw - 0.5, wr.grad) < tol, (mode, view, tile, sp, cfg)
+                        ops.conv_wgrad(plan, xin, dyd, dw, accumulate=False)
+                        assert rel_err(dw, wr.grad) < tol, (mode, view, tile, sp, cfg)
+        ops.set_conv_math('f32')
+        plan = ops.ConvPlan(N, C, D, Hh, W, K, (kd, 1, 1), 1, (pd, 0, 0), DEV)
+        plan.tuned = [True, True, True]
+        plan.g.tune_wgrad_tile = 11
+        plan.refresh()
+        assert plan.cfg(2)[3] & 255 != 11                                              # falls back to a conv_wgrad_kernel shape
+        dw = torch.zeros_like(w).to(DEV)
+        ops.conv_wgrad(plan, xd.contiguous(), dyd, dw, accumulate=True)
+        assert rel_err(dw, wr.grad) < 1e-5
+    finally:
+        ops.set_conv_math(default)

@@ -561,7 +561,7 @@ inline bool wgrad_shape_ok(int idx, int fast) {
   return idx <= 4;
 }
 
-struct WgradPlan { WgradParams p; int shape; bool avec; int fast; bool bvec; };
+struct WgradPlan { WgradParams p; int shape; bool avec; int fast; bool bvec; int ts; };   // ts: 11 / 12 = streaming temporal kernel
 
 void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   WgradParams& p = pl.p;
@@ -588,6 +588,21 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   pl.bvec = pl.avec && pl.fast == 1 && g->kh == 1 && g->kw == 1 && g->sh == 1 && g->sw == 1 && g->ph == 0 && g->pw == 0 &&
             (g->OH * g->OW) % 4 == 0 && cdhw % 4 == 0 && p.x_nstride % 4 == 0;
   p.kt_total = (int)gca_ceil_div((long long)p.Ktot, WBK);
+  p.math = resolve_math(g->tune_wgrad_math, g->act_f16);
+  p.half = p.math == 3;
+  pl.ts = 0;
+  if (g->tune_wgrad_tile >= 11 && wgrad_ts_ok(g, g->tune_wgrad_tile, p.math)) {
+    // conv3d_wgrad_ts.hip: its own tiling (32*TM x 32 x all taps per wave) and split (over clip x position-chunk units)
+    pl.ts = g->tune_wgrad_tile;
+    pl.shape = 0;
+    const int tm = pl.ts == 12 ? 2 : 1;
+    p.tilesM = (int)gca_ceil_div(g->K, 32 * tm);
+    p.tilesN = (int)gca_ceil_div(g->C, 32);
+    p.splits = wgrad_ts_splits(g, pl.ts, g->tune_wgrad_splits);
+    p.kt_per_split = 0;
+    p.chk = 0;
+    return;
+  }
   // tile shape: least padded MFMA work, discounted for how well a shape amortises its gathers
   int best = 0;
   if (wgrad_shape_ok(g->tune_wgrad_tile, pl.fast)) best = g->tune_wgrad_tile;
@@ -616,8 +631,6 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   if (g->tune_wgrad_splits > 0) want = g->tune_wgrad_splits < p.kt_total ? g->tune_wgrad_splits : p.kt_total;
   p.kt_per_split = (int)gca_ceil_div(p.kt_total, want);
   p.splits = (int)gca_ceil_div(p.kt_total, p.kt_per_split);
-  p.math = resolve_math(g->tune_wgrad_math, g->act_f16);
-  p.half = p.math == 3;
   p.chk = ((g->pd > 0 || (g->OD - 1) * g->sd + g->kd > g->D) ? 1 : 0) |
           ((g->ph > 0 || (g->OH - 1) * g->sh + g->kh > g->H) ? 2 : 0) |
           ((g->pw > 0 || (g->OW - 1) * g->sw + g->kw > g->W) ? 4 : 0);
@@ -679,6 +692,11 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
   if (!geom_ok(g) || !out4) return GCA_EINVAL;
   WgradPlan pl{};
   wgrad_plan(g, pl);
+  if (pl.ts) {
+    out4[0] = pl.ts == 12 ? 64 : 32; out4[1] = 32 * g->kd; out4[2] = pl.p.splits;
+    out4[3] = pl.ts | (pl.p.math << 12);
+    return GCA_OK;
+  }
   out4[0] = WGRAD_SHAPES[pl.shape].bm; out4[1] = WGRAD_SHAPES[pl.shape].bn; out4[2] = pl.p.splits;
   out4[3] = pl.shape | (pl.avec << 8) | (pl.fast << 9) | (pl.bvec << 11) | (pl.p.math << 12);
   return GCA_OK;
@@ -699,6 +717,19 @@ int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, cons
   float* slab = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)nblk);
   int rc;
+  if (pl.ts) {
+    if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return GCA_EINVAL;      // 16-byte DMA pieces
+    rc = wgrad_ts_launch(g, pl.ts, p.math, p.splits, x, dy, slab, st);
+    if (rc) return rc;
+    const long long n_ = (long long)g->K * p.Kred;
+    if (n_ % 4 == 0 && ((uintptr_t)slab % 16) == 0 && ((uintptr_t)dw % 16) == 0)
+      hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)gca_ceil_div(n_ / 4, 64)), dim3(256), 0, st,
+                         reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(dw), n_ / 4, p.splits, accumulate ? 1 : 0);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n_, 64)), dim3(256), 0, st, slab, dw, n_,
+                         p.splits, accumulate ? 1 : 0);
+    return gca_launch_status();
+  }
   const int av = !pl.avec || ((uintptr_t)dy % 16) ? 0 : (pl.bvec && ((uintptr_t)x % 16) == 0 ? 2 : 1);
   if (pl.fast == 1) rc = launch_shape<1>(pl.shape, av, grid, st, x, dy, t, slab, p);
   else if (pl.fast == 2) rc = launch_shape<2>(pl.shape, av, grid, st, x, dy, t, slab, p);

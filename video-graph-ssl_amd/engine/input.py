@@ -87,25 +87,24 @@ class DeviceInputStage(object):
     def out_shape(self):
         return (self.b, 3 * self.views, self.T, self.H, self.W)
 
-    def stage(self, frames, params):
-        """frames: (b, views, T, Hs, Ws, 3) uint8 host tensor / ndarray; params: (b, views, >=3) integers {h0, w0, flip}
-        (crop origin inside the source frame, flip decision).  Starts the asynchronous copy; returns a StagedBatch."""
-        f = torch.as_tensor(frames)
-        p = torch.as_tensor(np.asarray(params))
-        if tuple(f.shape) != tuple(self._host[0].shape) or f.dtype is not torch.uint8:
-            raise ValueError('frames must be uint8 of shape %r, got %s %r' % (tuple(self._host[0].shape), f.dtype, tuple(f.shape)))
-        if p.dim() != 3 or tuple(p.shape[:2]) != (self.b, self.views) or p.shape[2] < 3:
-            raise ValueError('params must be (b, views, >=3): h0, w0, flip')
-        h0, w0 = p[..., 0], p[..., 1]
-        if int(h0.min()) < 0 or int(w0.min()) < 0 or int(h0.max()) > self.Hs - self.H or int(w0.max()) > self.Ws - self.W:
-            raise ValueError('crop window outside the source frame')
+    def acquire(self):
+        """-> (frames, params): the pinned host buffers of the next slot -- (b, views, T, Hs, Ws, 3) uint8 and (b, views, 4)
+        int32 {h0, w0, flip, 0} -- for the loader to fill IN PLACE (decoded frames land in pinned memory once; no second host
+        copy).  Blocks only if the slot's previous H2D copy is still in flight.  Follow with submit()."""
+        s = self._next
+        if self._copied[s] is not None:
+            self._copied[s].synchronize()            # the pinned buffers of this slot are about to be overwritten by the host
+        return self._host[s], self._hostp[s]
+
+    def submit(self, check=True):
+        """Start the asynchronous H2D copy of the slot handed out by the last acquire(); returns a StagedBatch."""
         s = self._next
         self._next = (s + 1) % len(self._host)
-        if self._copied[s] is not None:
-            self._copied[s].synchronize()            # the pinned buffer of this slot is being re-filled by the host
-        self._host[s].copy_(f)
-        self._hostp[s].zero_()
-        self._hostp[s][..., :3].copy_(p[..., :3].to(torch.int32))
+        if check:
+            p = self._hostp[s]
+            if (int(p[..., 0].min()) < 0 or int(p[..., 1].min()) < 0 or int(p[..., 0].max()) > self.Hs - self.H
+                    or int(p[..., 1].max()) > self.Ws - self.W):
+                raise ValueError('crop window outside the source frame')
         with torch.cuda.stream(self.copy_stream):
             if self._consumed[s] is not None:
                 self.copy_stream.wait_event(self._consumed[s])    # the kernel that read this device slot has been issued and passed
@@ -115,6 +114,21 @@ class DeviceInputStage(object):
             ready.record(self.copy_stream)
         self._copied[s] = ready
         return StagedBatch(self, s, self._dev[s], self._devp[s], ready)
+
+    def stage(self, frames, params):
+        """Convenience for callers that hold the batch elsewhere: frames (b, views, T, Hs, Ws, 3) uint8 host tensor / ndarray,
+        params (b, views, >=3) integers {h0, w0, flip}.  = acquire() + one host copy into the pinned slot + submit()."""
+        f = torch.as_tensor(frames)
+        p = torch.as_tensor(np.asarray(params))
+        if tuple(f.shape) != tuple(self._host[0].shape) or f.dtype is not torch.uint8:
+            raise ValueError('frames must be uint8 of shape %r, got %s %r' % (tuple(self._host[0].shape), f.dtype, tuple(f.shape)))
+        if p.dim() != 3 or tuple(p.shape[:2]) != (self.b, self.views) or p.shape[2] < 3:
+            raise ValueError('params must be (b, views, >=3): h0, w0, flip')
+        hf, hp = self.acquire()
+        hf.copy_(f)
+        hp.zero_()
+        hp[..., :3].copy_(p[..., :3].to(torch.int32))
+        return self.submit()
 
     def prepare(self, staged, out):
         """Compute stream: wait for the copy, then crop + flip + normalise + layout change into `out`."""

@@ -202,6 +202,18 @@ class ConvPlan:
                 if sp * M * Nred * 4 > (256 << 20):
                     continue
                 cands.append((idx, sp))
+        # the streaming temporal kernel (conv3d_wgrad_ts.hip: tile 11 = 32, 12 = 64 output channels per wave); its split
+        # is over (clip, 16-position chunk) units.  The library refuses it where it does not apply (fp32-MFMA mode, ...).
+        g = self.g
+        hw = g.H * g.W
+        if (g.kh, g.kw, g.sd, g.sh, g.sw, g.ph, g.pw) == (1, 1, 1, 1, 1, 0, 0) and g.kd in (3, 7) and hw % 16 == 0 and not g.act_f16:
+            units = g.N * (hw // 16)
+            for idx, tm in ((11, 1), (12, 2)):
+                if idx == 12 and g.kd == 7:
+                    continue
+                tiles = -(-M // (32 * tm)) * -(-g.C // 32)
+                for nb in (256, 512, 1024):
+                    cands.append((idx, max(1, min(units // 4, -(-nb // tiles)))))
         return sorted(set(cands))
 
     # ---- one-off launch tuning ------------------------------------------------------------
