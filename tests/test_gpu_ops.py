@@ -903,3 +903,54 @@ def test_conv_wgrad_streaming_temporal_kernel(ops, shape, K, kd, pd):
         assert rel_err(dw, wr.grad) < 1e-5
     finally:
         ops.set_conv_math(default)
+
+
+@pytest.mark.parametrize('shape,K', [
+    ((2, 40, 3, 8, 28), 48),        # W = 28: two chunks per row, the second one ragged; C, K tile tails
+    ((3, 33, 2, 5, 16), 70),        # one full chunk per row, odd unit count
+    ((2, 64, 1, 9, 4), 32),         # W = 4: one quad per row
+    ((1, 20, 2, 2, 56), 40),        # H = 2 (every row touches the padding), four chunks
+    ((4, 32, 4, 28, 28), 144),      # the layer-1 kind of R(2+1)D-18 at small batch
+])
+def test_conv_wgrad_streaming_spatial_kernel(ops, shape, K):
+    """conv3d_wgrad_ts.hip, tune_wgrad_tile 13: the streaming weight gradient of (1,3,3) / pad 1 / unit-stride convs (three-row
+    register window, column shifts cut out of one wide fragment read, zero padding by the DMA's range check) over split counts
+    from one workgroup to one unit per wave, both split-product arithmetics, += and a batch-strided x view, vs ATen in fp64."""
+    torch.manual_seed(shape[1] * 7 + shape[4])
+    N, C, D, Hh, W = shape
+    big = torch.randn(N, 2 * C, D, Hh, W)
+    x = big[:, C:]
+    w = torch.randn(K, C, 1, 3, 3) * 0.1
+    xr, wr = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, 1, (0, 1, 1))
+    dy = torch.randn(yr.shape)
+    yr.backward(dy.double())
+    units = N * D * -(-W // 16)
+    default = ops.get_conv_math()
+    bigd, dyd = big.to(DEV), dy.to(DEV)
+    xd = bigd[:, C:]
+    try:
+        for mode, tol in (('bf16x6', 1e-5), ('bf16x3', 5e-5)):
+            ops.set_conv_math(mode)
+            for view in (False, True):
+                xin = xd if view else xd.contiguous()
+                plan = ops.ConvPlan(N, C, D, Hh, W, K, (1, 3, 3), 1, (0, 1, 1), DEV, x_batch_stride=xin.stride(0) if view else 0)
+                plan.tuned = [True, True, True]
+                for sp in sorted({1, 2, max(1, units // 8), max(1, units // 4)}):
+                    plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = 13, sp
+                    plan.refresh()
+                    cfg = plan.cfg(2)
+                    assert cfg[3] & 255 == 13, cfg
+                    dw = torch.full_like(w, 0.5).to(DEV)
+                    ops.conv_wgrad(plan, xin, dyd, dw, accumulate=True)
+                    assert rel_err(dw - 0.5, wr.grad) < tol, (mode, view, sp, cfg)
+                    ops.conv_wgrad(plan, xin, dyd, dw, accumulate=False)
+                    assert rel_err(dw, wr.grad) < tol, (mode, view, sp, cfg)
+        # geometries it must refuse: W % 4 != 0, strides
+        for shp, s in (((2, 16, 2, 6, 14), 1), ((2, 16, 2, 8, 28), (1, 2, 2))):
+            plan = ops.ConvPlan(*shp, 32, (1, 3, 3), s, (0, 1, 1), DEV)
+            plan.g.tune_wgrad_tile = 13
+            plan.refresh()
+            assert plan.cfg(2)[3] & 255 != 13
+    finally:
+        ops.set_conv_math(default)

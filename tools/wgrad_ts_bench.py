@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module('video-graph-ssl_amd')
 ops = pkg.engine.ops
 DEV = torch.device('cuda:0')
-LAYERS = [('L01', (32, 110, 16, 56, 56), 64, 7, 3), ('L03', (32, 144, 8, 28, 28), 64, 3, 1), ('L32', (32, 1152, 1, 4, 4), 512, 3, 1)]
+LAYERS = [('L01', (32, 110, 16, 56, 56), 64, 7, 3), ('L03', (32, 144, 8, 28, 28), 64, 3, 1)]
+SPATIAL = [('L02', (32, 64, 8, 28, 28), 144), ('L30', (32, 512, 1, 4, 4), 1152)]
 
 
 def time_ms(fn, reps=10):
@@ -67,5 +68,34 @@ def main():
             print('%s %-52s %8.4f ms %7.1f TF/s' % (name, what, ms, flops / 1e9 / ms))
 
 
+def spatial():
+    for name, shape, K in SPATIAL:
+        N, C, D, H, W = shape
+        x = torch.randn(shape, device=DEV)
+        plan = ops.ConvPlan(N, C, D, H, W, K, (1, 3, 3), 1, (0, 1, 1), DEV)
+        dy = torch.randn(plan.out_shape, device=DEV)
+        dw = torch.zeros(K, C, 1, 3, 3, device=DEV)
+        flops = 2.0 * N * K * D * H * W * C * 9
+        plan.tuned = [True, True, True]
+        rows = []
+        for tile, sp in ((6, 102), (6, 64), (4, 64), (9, 64)):
+            plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = tile, sp
+            plan.refresh()
+            rows.append(('conv_wgrad_kernel %s' % (plan.cfg(2)[:3],), time_ms(lambda: ops._conv_wgrad_launch(plan, x, dy, dw, False))))
+        units = N * D * -(-W // 16)
+        tiles = -(-K // 32) * -(-C // 32)
+        for nb in (128, 256, 512, 768, 1024):
+            sp = max(1, min(units // 4, nb // tiles))
+            plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = 13, sp
+            plan.refresh()
+            if plan.cfg(2)[3] & 255 != 13:
+                continue
+            rows.append(('ss tile 13 splits %d (blocks %d)' % (plan.cfg(2)[2], plan.cfg(2)[2] * tiles),
+                         time_ms(lambda: ops._conv_wgrad_launch(plan, x, dy, dw, False))))
+        for what, ms in rows:
+            print('%s %-52s %8.4f ms %7.1f TF/s' % (name, what, ms, flops / 1e9 / ms))
+
+
 if __name__ == '__main__':
+    spatial()
     main()

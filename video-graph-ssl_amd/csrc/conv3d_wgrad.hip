@@ -693,7 +693,7 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
   WgradPlan pl{};
   wgrad_plan(g, pl);
   if (pl.ts) {
-    out4[0] = pl.ts == 12 ? 64 : 32; out4[1] = 32 * g->kd; out4[2] = pl.p.splits;
+    out4[0] = pl.ts == 12 ? 64 : 32; out4[1] = 32 * taps(g); out4[2] = pl.p.splits;
     out4[3] = pl.ts | (pl.p.math << 12);
     return GCA_OK;
   }

@@ -100,7 +100,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   for (int v : {g->tune_fwd_box, g->tune_dgrad_box}) if (v < 0 || v > 0xffffff) return false;
   if (g->act_f16 != 0 && g->act_f16 != 1) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
-  if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 12) return false;     // 1..10 tile shapes of conv_wgrad_kernel, 11 / 12 the streaming temporal kernel
+  if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 13) return false;     // 1..10 tile shapes of conv_wgrad_kernel, 11 / 12 the streaming temporal kernel, 13 the streaming (1,3,3) kernel
   for (int v : {g->tune_fwd_math, g->tune_dgrad_math, g->tune_wgrad_math}) if (v < 0 || v > 3) return false;
   for (int v : {g->tune_fwd_tail, g->tune_dgrad_tail}) if (v < 0 || (v != 0 && ((v & 255) < 1 || (v & 255) > 4))) return false;
   return true;
