@@ -149,6 +149,24 @@ int gca_conv_dgrad(const gca_conv_geom* g, const void* dy, const float* wpack, c
 int64_t gca_conv_wgrad_ws_bytes(const gca_conv_geom* g);
 int gca_conv_wgrad(const gca_conv_geom* g, const void* x, const void* dy, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream);
+/* The same in two halves, so that the fixed-order reductions of MANY layers run as ONE launch at the end of the backward
+ * pass (the reference gets a weight gradient per cuDNN call; here 39 per-layer reduce launches of 8-12 us are pure
+ * latency): gca_conv_wgrad_partial leaves the `*out_splits` fp32 slabs in `slabs` (gca_conv_wgrad_ws_bytes, caller-owned,
+ * must stay untouched until reduced); gca_splitk_reduce_batched does dw (+)= sum of slabs for every job, bit-identical
+ * to gca_conv_wgrad's own reduction.  Jobs: fill slabs / dw / n (= K*C*taps) / splits / accumulate on the host, call
+ * gca_reduce_jobs_finalize_host (assigns block ranges, returns the grid size), copy the records to the device once.
+ * Two jobs of one launch must not write the same dw. */
+typedef struct {
+  const float* slabs;
+  float* dw;
+  int64_t n;
+  int32_t splits, accumulate;
+  int32_t first_block, nblocks;     /* filled by gca_reduce_jobs_finalize_host */
+} gca_reduce_job;
+int gca_conv_wgrad_partial(const gca_conv_geom* g, const void* x, const void* dy, const int32_t* table, void* slabs,
+                           int32_t* out_splits, void* stream);
+int64_t gca_reduce_jobs_finalize_host(gca_reduce_job* jobs, int64_t njobs);
+int gca_splitk_reduce_batched(const gca_reduce_job* jobs_dev, int64_t njobs, int64_t total_blocks, void* stream);
 /* Launch shape the wgrad kernel will use for g: out4 = {tile rows (output channels), tile columns (C*taps),
  * split-K factor, shape index | float4 dY loads<<8 | tap-mask kind<<9 | float4 X gathers<<11 | arithmetic<<12}. */
 int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4);

@@ -379,3 +379,40 @@ def test_process_exits_cleanly_with_live_graphs(pkg):
     r = subprocess.run([sys.executable, '-c', _EXIT_SCRIPT % {'root': ROOT}], capture_output=True, text=True, timeout=600)
     assert 'EXIT-OK' in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize('kind', ['moco', 'simsiam'])
+def test_deferred_splitk_reduction_is_bit_identical(pkg, kind):
+    """The weight-gradient split-K reductions of a backward pass collected into ONE launch (ops.DeferredReduce,
+    gca_conv_wgrad_partial + gca_splitk_reduce_batched) against one reduce launch per layer: same slabs, same fold order --
+    losses and every parameter bit for bit after five steps (eager, eager, capture, replays).  SimSiam sends both views
+    through one encoder, i.e. two gradients per weight and backward pass: the collector must keep their += order."""
+    trainer_mod = importlib.import_module('video-graph-ssl_amd.engine.trainer')
+    parity.register_tiny(pkg)
+    gen = torch.Generator().manual_seed(15)
+    xs = [torch.randn(8, 6, 8, 48, 48, generator=gen).to(DEV) for _ in range(5)]
+    runs = []
+    default = trainer_mod.DEFER_REDUCE
+    try:
+        for defer in (True, False):
+            trainer_mod.DEFER_REDUCE = defer
+            if kind == 'moco':
+                tr = pkg.MoCoTrainer(parity.make_cfg(pkg, 'R2P1D10T', 'moco', 32, 64, 8), DEV, use_graph=True, seed=4)
+                arena = tr.arena_q
+            else:
+                tr = pkg.SimSiamTrainer(parity.make_cfg(pkg, 'R2P1D10T', 'simsiam', 32, 16, 8), DEV, use_graph=True, seed=4)
+                arena = tr.arena
+            losses = [tr.train_step(x)['loss'].clone() for x in xs]
+            torch.cuda.synchronize()
+            d = getattr(tr, '_deferred', None)
+            assert (d is not None and d.launches >= 2) == defer            # (eager steps; replays do not pass through Python)
+            if defer and kind == 'simsiam':
+                assert d.launches >= 4                                      # two flushes per backward pass: the shared weights
+            runs.append((losses, arena.flat.clone(), tr.optimizer.buf.clone()))
+            tr.close()
+    finally:
+        trainer_mod.DEFER_REDUCE = default
+    (la, pa, ba), (lb, pb, bb) = runs
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    assert torch.equal(pa, pb) and torch.equal(ba, bb)

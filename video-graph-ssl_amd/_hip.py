@@ -103,6 +103,9 @@ SIGNATURES = {
     'gca_sgd_step': (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_i32, c_i32, c_vp, c_vp]),
     'gca_grad_clip_ws_bytes': (c_i64, []),
     'gca_grad_clip_coef': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_vp, c_vp]),
+    'gca_conv_wgrad_partial': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'gca_reduce_jobs_finalize_host': (c_i64, [c_vp, c_i64]),
+    'gca_splitk_reduce_batched': (c_i32, [c_vp, c_i64, c_i64, c_vp]),
     'gca_clip_prepare': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),
     'gca_rank_ge': (c_i32, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'gca_grad_unscale_clip': (c_i32, [c_vp, c_i64, c_f32, c_vp, c_f32, c_f32, c_i32, c_f32, c_vp, c_vp, c_vp]),
@@ -123,6 +126,11 @@ for _name, (_res, _args) in SIGNATURES.items():
 
 
 PACK_JOB_BYTES = 128      # GCA_PACK_JOB_BYTES
+
+
+class ReduceJob(C.Structure):      # gca_reduce_job
+    _fields_ = [('slabs', C.c_void_p), ('dw', C.c_void_p), ('n', C.c_int64), ('splits', C.c_int32), ('accumulate', C.c_int32),
+                ('first_block', C.c_int32), ('nblocks', C.c_int32)]
 
 
 def ptr(t, half_ok=False):

@@ -530,6 +530,89 @@ __global__ __launch_bounds__(256) void splitk_reduce4_kernel(const float4* __res
   }
 }
 
+// The same two reductions for MANY weight gradients in one launch (gca_splitk_reduce_batched): a block looks its job up by
+// block range and then does exactly what a block of splitk_reduce4_kernel / splitk_reduce_kernel does for that job -- same
+// slabs per wave, same fold order, hence the same bits as the per-layer launches.  39 launches of 8-12 us each (all latency)
+// become one.
+struct ReduceJob { const float* slabs; float* dw; long long n; int splits; int accumulate; int first_block; int nblocks; };
+static_assert(sizeof(ReduceJob) == sizeof(gca_reduce_job), "gca_hip.h: gca_reduce_job layout");
+__global__ __launch_bounds__(256) void splitk_reduce_batched_kernel(const ReduceJob* __restrict__ jobs, int njobs) {
+  __shared__ float4 sh[4][64];
+  const int bid = blockIdx.x;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= bid) lo = mid; else hi = mid - 1;
+  }
+  const ReduceJob j = jobs[lo];
+  const int blk = bid - j.first_block;
+  const int x = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int splits = j.splits;
+  if (j.n % 4 == 0) {                                   // (host: vector form only when slabs / dw are 16-byte aligned)
+    const long long n4 = j.n >> 2, i = (long long)blk * 64 + x;
+    const float4* slab = reinterpret_cast<const float4*>(j.slabs);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      int k = y;
+      for (; k + 60 < splits; k += 64) {
+        float4 l[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) l[u] = slab[(long long)(k + 4 * u) * n4 + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { s.x += l[u].x; s.y += l[u].y; s.z += l[u].z; s.w += l[u].w; }
+      }
+      for (; k + 12 < splits; k += 16) {
+        const float4 l0 = slab[(long long)k * n4 + i], l1 = slab[(long long)(k + 4) * n4 + i];
+        const float4 l2 = slab[(long long)(k + 8) * n4 + i], l3 = slab[(long long)(k + 12) * n4 + i];
+        s.x += l0.x; s.y += l0.y; s.z += l0.z; s.w += l0.w;
+        s.x += l1.x; s.y += l1.y; s.z += l1.z; s.w += l1.w;
+        s.x += l2.x; s.y += l2.y; s.z += l2.z; s.w += l2.w;
+        s.x += l3.x; s.y += l3.y; s.z += l3.z; s.w += l3.w;
+      }
+      for (; k < splits; k += 4) {
+        const float4 l = slab[(long long)k * n4 + i];
+        s.x += l.x; s.y += l.y; s.z += l.z; s.w += l.w;
+      }
+    }
+    sh[y][x] = s;
+    __syncthreads();
+    if (y == 0 && i < n4) {
+      const float4 a = sh[0][x], b = sh[1][x], c = sh[2][x], d = sh[3][x];
+      float4 t = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+      float4* dw = reinterpret_cast<float4*>(j.dw);
+      if (j.accumulate) { const float4 o = dw[i]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+      dw[i] = t;
+    }
+  } else {
+    float* shs = reinterpret_cast<float*>(&sh[0][0]);   // [4][64] floats
+    const long long i = (long long)blk * 64 + x;
+    float s = 0.f;
+    if (i < j.n) {
+      int k = y;
+      for (; k + 60 < splits; k += 64) {
+        float l[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) l[u] = j.slabs[(long long)(k + 4 * u) * j.n + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += l[u];
+      }
+      for (; k + 12 < splits; k += 16) {
+        const float l0 = j.slabs[(long long)k * j.n + i], l1 = j.slabs[(long long)(k + 4) * j.n + i];
+        const float l2 = j.slabs[(long long)(k + 8) * j.n + i], l3 = j.slabs[(long long)(k + 12) * j.n + i];
+        s += l0; s += l1; s += l2; s += l3;
+      }
+      for (; k < splits; k += 4) s += j.slabs[(long long)k * j.n + i];
+    }
+    shs[y * 64 + x] = s;
+    __syncthreads();
+    if (y == 0 && i < j.n) {
+      float t = (shs[x] + shs[64 + x]) + (shs[128 + x] + shs[192 + x]);
+      if (j.accumulate) t += j.dw[i];
+      j.dw[i] = t;
+    }
+  }
+}
+
 __global__ void bias_grad_kernel(const float* __restrict__ dy, long long N, long long K, long long SP,
                                  float* __restrict__ db, int accumulate) {
   __shared__ float sh[4];
@@ -702,15 +785,15 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
   return GCA_OK;
 }
 
-int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, const int32_t* table,
-                   float* dw, int accumulate, void* ws, void* stream) {
+// the split-K kernel of `g` into `slab` (gca_conv_wgrad_ws_bytes); -> splits (> 0) or a negative status
+static int wgrad_partial_launch(const gca_conv_geom* g, const void* x_, const void* dy_, const int32_t* table, void* ws,
+                                hipStream_t st) {
   const float* x = reinterpret_cast<const float*>(x_);      // opaque to the host side: the kernels index in bytes
   const float* dy = reinterpret_cast<const float*>(dy_);
-  if (!geom_ok(g) || !x || !dy || !table || !dw || !ws) return GCA_EINVAL;
+  if (!geom_ok(g) || !x || !dy || !table || !ws) return GCA_EINVAL;
   WgradPlan pl{};
   wgrad_plan(g, pl);
   const WgradParams& p = pl.p;
-  hipStream_t st = (hipStream_t)stream;
   const long long nblk = (long long)p.tilesM * p.tilesN * p.splits;
   if (nblk > 0x7fffffffLL) return GCA_EINVAL;
   const int2* t = reinterpret_cast<const int2*>(table);
@@ -720,15 +803,7 @@ int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, cons
   if (pl.ts) {
     if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return GCA_EINVAL;      // 16-byte DMA pieces
     rc = wgrad_ts_launch(g, pl.ts, p.math, p.splits, x, dy, slab, st);
-    if (rc) return rc;
-    const long long n_ = (long long)g->K * p.Kred;
-    if (n_ % 4 == 0 && ((uintptr_t)slab % 16) == 0 && ((uintptr_t)dw % 16) == 0)
-      hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)gca_ceil_div(n_ / 4, 64)), dim3(256), 0, st,
-                         reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(dw), n_ / 4, p.splits, accumulate ? 1 : 0);
-    else
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n_, 64)), dim3(256), 0, st, slab, dw, n_,
-                         p.splits, accumulate ? 1 : 0);
-    return gca_launch_status();
+    return rc ? rc : p.splits;
   }
   const int av = !pl.avec || ((uintptr_t)dy % 16) ? 0 : (pl.bvec && ((uintptr_t)x % 16) == 0 ? 2 : 1);
   if (pl.fast == 1) rc = launch_shape<1>(pl.shape, av, grid, st, x, dy, t, slab, p);
@@ -736,14 +811,56 @@ int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, cons
   else rc = launch_shape<0>(pl.shape, av, grid, st, x, dy, t, slab, p);
   if (rc) return rc;
   rc = gca_launch_status();
-  if (rc) return rc;
-  const long long n = (long long)g->K * p.Kred;
+  return rc ? rc : p.splits;
+}
+
+int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, const int32_t* table,
+                   float* dw, int accumulate, void* ws, void* stream) {
+  if (!dw) return GCA_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = wgrad_partial_launch(g, x_, dy_, table, ws, st);
+  if (splits < 0) return splits;
+  float* slab = reinterpret_cast<float*>(ws);
+  const long long n = (long long)g->K * g->C * taps(g);
   if (n % 4 == 0 && ((uintptr_t)slab % 16) == 0 && ((uintptr_t)dw % 16) == 0)
     hipLaunchKernelGGL(splitk_reduce4_kernel, dim3((unsigned)gca_ceil_div(n / 4, 64)), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(dw), n / 4, p.splits, accumulate ? 1 : 0);
+                       reinterpret_cast<const float4*>(slab), reinterpret_cast<float4*>(dw), n / 4, splits, accumulate ? 1 : 0);
   else
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gca_ceil_div(n, 64)), dim3(256), 0, st, slab, dw, n,
-                       p.splits, accumulate ? 1 : 0);
+                       splits, accumulate ? 1 : 0);
+  return gca_launch_status();
+}
+
+int gca_conv_wgrad_partial(const gca_conv_geom* g, const void* x, const void* dy, const int32_t* table, void* slabs,
+                           int32_t* out_splits, void* stream) {
+  if (!out_splits) return GCA_EINVAL;
+  const int splits = wgrad_partial_launch(g, x, dy, table, slabs, (hipStream_t)stream);
+  if (splits < 0) return splits;
+  *out_splits = splits;
+  return GCA_OK;
+}
+
+int64_t gca_reduce_jobs_finalize_host(gca_reduce_job* jobs, int64_t njobs) {
+  if (!jobs || njobs <= 0) return GCA_EINVAL;
+  long long first = 0;
+  for (int64_t i = 0; i < njobs; ++i) {
+    gca_reduce_job& j = jobs[i];
+    if (!j.slabs || !j.dw || j.n <= 0 || j.splits <= 0) return GCA_EINVAL;
+    // the vector form needs 16-byte aligned slabs / dw; otherwise n % 4 != 0 must hold for the kernel to take the scalar form
+    if (j.n % 4 == 0 && (((uintptr_t)j.slabs % 16) || ((uintptr_t)j.dw % 16))) return GCA_EINVAL;
+    const long long nb = j.n % 4 == 0 ? gca_ceil_div(j.n / 4, 64) : gca_ceil_div(j.n, 64);
+    if (first + nb > 0x7fffffffLL) return GCA_EINVAL;
+    j.first_block = (int32_t)first;
+    j.nblocks = (int32_t)nb;
+    first += nb;
+  }
+  return first;
+}
+
+int gca_splitk_reduce_batched(const gca_reduce_job* jobs_dev, int64_t njobs, int64_t total_blocks, void* stream) {
+  if (!jobs_dev || njobs <= 0 || total_blocks <= 0 || total_blocks > 0x7fffffffLL) return GCA_EINVAL;
+  hipLaunchKernelGGL(splitk_reduce_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const ReduceJob*>(jobs_dev), (int)njobs);
   return gca_launch_status();
 }
 

@@ -501,10 +501,71 @@ def _conv_wgrad_launch(plan, x, dy, dw, accumulate):
     H.call('gca_conv_wgrad', plan.gp, _act(plan, x), _act(plan, dy), ptr(plan.table(2)), ptr(dw), int(accumulate), ptr(ws), stream())
 
 
+class DeferredReduce(object):
+    """Collects the split-K reductions of the weight gradients of one backward pass (stage) and runs them as ONE launch
+    (gca_splitk_reduce_batched) instead of one 8-12 us launch per layer.  Each (gradient tensor, plan) pair owns a
+    persistent slab buffer (the partial sums must survive until the flush); the job table of a given set of layers is
+    built and uploaded once -- during the eager warm-up steps -- and replayed from then on, hipGraph capture included.
+    Results are bit-identical to the per-layer reductions (same fold order)."""
+
+    def __init__(self):
+        self.slabs = {}          # (dw data_ptr, plan id) -> uint8 slab buffer
+        self.tables = {}         # tuple of job signatures -> (device table, njobs, blocks)
+        self.pending = []        # [(slab, dw, n, splits, accumulate)]
+        self.launches = 0
+
+    def slab_for(self, dw, plan):
+        key = (dw.data_ptr(), id(plan))
+        b = self.slabs.get(key)
+        if b is None or b.numel() < plan.wgrad_ws:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('weight-gradient slab would be allocated during graph capture; run one eager step first')
+            b = self.slabs[key] = torch.empty(max(int(plan.wgrad_ws), 16), dtype=torch.uint8, device=dw.device)
+        return b
+
+    def add(self, plan, x, dy, dw, accumulate):
+        if any(j[1].data_ptr() == dw.data_ptr() for j in self.pending):
+            self.flush()                                   # a weight used twice (SimSiam's two views): keep the += order, no race
+        slab = self.slab_for(dw, plan)
+        splits = C.c_int32(0)
+        H.call('gca_conv_wgrad_partial', plan.gp, _act(plan, x), _act(plan, dy), ptr(plan.table(2)), slab.data_ptr(),
+               C.addressof(splits), stream())
+        self.pending.append((slab, dw, dw.numel(), int(splits.value), int(bool(accumulate))))
+
+    def flush(self):
+        if not self.pending:
+            return
+        jobs, self.pending = self.pending, []
+        sig = tuple((j[0].data_ptr(), j[1].data_ptr(), j[2], j[3], j[4]) for j in jobs)
+        t = self.tables.get(sig)
+        if t is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('reduce-job table would be built during graph capture; run one eager step first')
+            arr = (H.ReduceJob * len(jobs))()
+            for r, (slab, dw, n, splits, acc) in zip(arr, jobs):
+                r.slabs, r.dw, r.n, r.splits, r.accumulate = slab.data_ptr(), dw.data_ptr(), n, splits, acc
+            blocks = H.lib.gca_reduce_jobs_finalize_host(C.addressof(arr), len(jobs))
+            if blocks <= 0:
+                raise RuntimeError('gca_reduce_jobs_finalize_host: %d' % blocks)
+            dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(jobs[0][1].device)
+            t = self.tables[sig] = (dev, len(jobs), int(blocks))
+        H.call('gca_splitk_reduce_batched', t[0].data_ptr(), t[1], t[2], stream())
+        self.launches += 1
+
+
+# The collector of the backward pass that is running (set by the trainers around Tape.backward), or None: every
+# conv_wgrad then reduces its own slabs at once.
+DEFER = [None]
+
+
 def conv_wgrad(plan, x, dy, dw, accumulate=True):
     if not plan.tuned[2]:
         scratch = torch.empty_like(dw)
         plan.tune(2, lambda: _conv_wgrad_launch(plan, x, dy, scratch, False))
+    d = DEFER[0]
+    if d is not None and dw.is_contiguous():
+        d.add(plan, x, dy, dw, accumulate)
+        return dw
     _conv_wgrad_launch(plan, x, dy, dw, accumulate)
     return dw
 

@@ -53,3 +53,5 @@ class Tape:
             CURRENT[0] = len(self.fns) - 1
             self.fns.pop()()
         CURRENT[0] = -1
+        if ops.DEFER[0] is not None:
+            ops.DEFER[0].flush()          # the weight-gradient reductions of this stage: one launch (ops.DeferredReduce)

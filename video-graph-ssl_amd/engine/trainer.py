@@ -115,7 +115,25 @@ class _ShapeOnly(object):
         self.shape, self.device, self.dtype = torch.Size(shape), device, torch.float32
 
 
+# GCA_DEFER_REDUCE=0: every weight gradient reduces its split-K slabs in its own launch (A/B runs)
+DEFER_REDUCE = os.environ.get('GCA_DEFER_REDUCE', '1') != '0'
+
+
 class _TrainerBase(object):
+    def _backward(self, tape, upto):
+        """Tape.backward with the weight-gradient split-K reductions of the stage collected into one launch."""
+        if not DEFER_REDUCE:
+            return tape.backward(upto)
+        if getattr(self, '_deferred', None) is None:
+            self._deferred = ops.DeferredReduce()
+        if ops.DEFER[0] is not None:
+            raise RuntimeError('another backward pass is collecting weight-gradient reductions')
+        ops.DEFER[0] = self._deferred
+        try:
+            tape.backward(upto)
+        finally:
+            ops.DEFER[0] = None
+
     def _buckets_from_log(self, arena, log):
         """log: (backward closure index, parameter) pairs of one eager backward pass (engine.layers.GRAD_LOG).  Cuts the
         arena into buckets that a reverse sweep of the tape completes one after the other (parallel.plan_buckets)."""
@@ -259,13 +277,13 @@ class MoCoTrainer(_TrainerBase):
                                       ov_start_dev=self.ptr_dev)
         ops.queue_advance(self.ptr_dev, s['all_k'].shape[0], self.K)
         self.out = dict(loss=loss, logits=logits, rank=rank, q=qv.t)
-        tape.backward(upto)
+        self._backward(tape, upto)
         self._tape = tape if upto > 0 else None
         if upto == 0:
             self._unpack('q')
 
     def _phase_backward_stage(self, upto, last):
-        self._tape.backward(upto)
+        self._backward(self._tape, upto)
         if last:
             self._tape = None
             self._unpack('q')
@@ -471,7 +489,7 @@ class SimSiamTrainer(_TrainerBase):
         self.out = dict(loss=lv.t)
         ops.LOSS_SCALE_STATE[0] = self.scale_state            # fp16 storage: SimSiam.fwd's loss-gradient seed is scaled by S
         try:
-            tape.backward(upto)
+            self._backward(tape, upto)
         finally:
             ops.LOSS_SCALE_STATE[0] = None
         self._tape = tape if upto > 0 else None
@@ -481,7 +499,7 @@ class SimSiamTrainer(_TrainerBase):
     def _bwd_stage(self, upto, last):
         ops.LOSS_SCALE_STATE[0] = self.scale_state
         try:
-            self._tape.backward(upto)
+            self._backward(self._tape, upto)
         finally:
             ops.LOSS_SCALE_STATE[0] = None
         if last:
