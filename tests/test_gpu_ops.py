@@ -911,6 +911,9 @@ def test_conv_wgrad_streaming_temporal_kernel(ops, shape, K, kd, pd):
     ((2, 64, 1, 9, 4), 32),         # W = 4: one quad per row
     ((1, 20, 2, 2, 56), 40),        # H = 2 (every row touches the padding), four chunks
     ((4, 32, 4, 28, 28), 144),      # the layer-1 kind of R(2+1)D-18 at small batch
+    ((3, 40, 4, 14, 14), 96),       # W = 14: one chunk per row, tail columns masked in registers (layer-2 kind)
+    ((2, 33, 2, 7, 7), 64),         # W = 7
+    ((2, 32, 2, 6, 13), 32),        # odd W
 ])
 def test_conv_wgrad_streaming_spatial_kernel(ops, shape, K):
     """conv3d_wgrad_ts.hip, tune_wgrad_tile 13: the streaming weight gradient of (1,3,3) / pad 1 / unit-stride convs (three-row
@@ -946,8 +949,8 @@ def test_conv_wgrad_streaming_spatial_kernel(ops, shape, K):
                     assert rel_err(dw - 0.5, wr.grad) < tol, (mode, view, sp, cfg)
                     ops.conv_wgrad(plan, xin, dyd, dw, accumulate=False)
                     assert rel_err(dw, wr.grad) < tol, (mode, view, sp, cfg)
-        # geometries it must refuse: W % 4 != 0, strides
-        for shp, s in (((2, 16, 2, 6, 14), 1), ((2, 16, 2, 8, 28), (1, 2, 2))):
+        # geometries it must refuse: W % 4 != 0 beyond one chunk, strides
+        for shp, s in (((2, 16, 2, 6, 18), 1), ((2, 16, 2, 8, 28), (1, 2, 2))):
             plan = ops.ConvPlan(*shp, 32, (1, 3, 3), s, (0, 1, 1), DEV)
             plan.g.tune_wgrad_tile = 13
             plan.refresh()

@@ -14,7 +14,7 @@ pkg = importlib.import_module('video-graph-ssl_amd')
 ops = pkg.engine.ops
 DEV = torch.device('cuda:0')
 LAYERS = [('L01', (32, 110, 16, 56, 56), 64, 7, 3), ('L03', (32, 144, 8, 28, 28), 64, 3, 1)]
-SPATIAL = [('L02', (32, 64, 8, 28, 28), 144), ('L30', (32, 512, 1, 4, 4), 1152)]
+SPATIAL = [('L02', (32, 64, 8, 28, 28), 144), ('L12', (32, 128, 4, 14, 14), 288), ('L21', (32, 256, 2, 7, 7), 576)]
 
 
 def time_ms(fn, reps=10):
@@ -78,7 +78,7 @@ def spatial():
         flops = 2.0 * N * K * D * H * W * C * 9
         plan.tuned = [True, True, True]
         rows = []
-        for tile, sp in ((6, 102), (6, 64), (4, 64), (9, 64)):
+        for tile, sp in ((6, 102), (6, 28), (5, 9), (4, 16)):
             plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = tile, sp
             plan.refresh()
             rows.append(('conv_wgrad_kernel %s' % (plan.cfg(2)[:3],), time_ms(lambda: ops._conv_wgrad_launch(plan, x, dy, dw, False))))

@@ -801,7 +801,9 @@ static int wgrad_partial_launch(const gca_conv_geom* g, const void* x_, const vo
   dim3 grid((unsigned)nblk);
   int rc;
   if (pl.ts) {
-    if (((uintptr_t)x % 16) || ((uintptr_t)dy % 16)) return GCA_EINVAL;      // 16-byte DMA pieces
+    // 16-byte DMA pieces; rows of the (1,3,3) kernel start at arbitrary columns anyway, so only dword alignment matters there
+    if (pl.ts != 13 && (((uintptr_t)x % 16) || ((uintptr_t)dy % 16))) return GCA_EINVAL;
+    if (((uintptr_t)x % 4) || ((uintptr_t)dy % 4)) return GCA_EINVAL;
     rc = wgrad_ts_launch(g, pl.ts, p.math, p.splits, x, dy, slab, st);
     return rc ? rc : p.splits;
   }

@@ -319,7 +319,10 @@ struct SsParams {
 // quads of a 32-row x 6-quad B piece set: slot s = 6 r + (q ^ sw6(r)); eight / sixteen consecutive rows read distinct columns
 __device__ __forceinline__ int sw6(int r) { return ((r >> 2) ^ (r >> 3)) & 1; }
 
-template <int TM, int MATH>
+// MASK: rows narrower than one chunk with W % 4 != 0 (W = 14: the layer-2 maps of R(2+1)D-18).  The last quad of a row then
+// also holds the first elements of the NEXT row; those columns (>= W) are zeroed in registers after the fragment read --
+// the same lanes and registers every step, since there is one chunk per row (w0 = 0).
+template <int TM, int MATH, bool MASK>
 __global__ __launch_bounds__(256) void conv_wgrad_ss_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ slab, const SsParams p) {
   static_assert(MATH == 1 || MATH == 2, "split-product arithmetic only");
@@ -470,6 +473,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_ss_kernel(const float* __restr
       const float4 v = *reinterpret_cast<const float4*>(st + fb[k]);
       rb[4 * k] = v.x; rb[4 * k + 1] = v.y; rb[4 * k + 2] = v.z; rb[4 * k + 3] = v.w;
     }
+    if constexpr (MASK) {                       // column of raw x element r: 8 lh + r - 4; of dY element e: 8 lh + e
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rb[r] = (8 * lh + r - 4 < p.W) ? rb[r] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ra[i][e] = (8 * lh + e < p.W) ? ra[i][e] : 0.f;
+    }
   };
   auto split_next = [&](int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -589,17 +600,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_ss_kernel(const float* __restr
       }
 }
 
-template <int TM>
+template <int TM, bool MASK>
 int launch_ss(int math, dim3 grid, size_t lds, hipStream_t st, const float* x, const float* dy, float* slab, const SsParams& p) {
   static bool raised[2] = {false, false};
 #define GCA_SS(M)                                                                                                          \
   {                                                                                                                        \
     if (!raised[M - 1]) {                                                                                                  \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ss_kernel<TM, M>),                                 \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_ss_kernel<TM, M, MASK>),                                 \
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10) != hipSuccess) return GCA_ELAUNCH;   \
       raised[M - 1] = true;                                                                                                \
     }                                                                                                                      \
-    hipLaunchKernelGGL((conv_wgrad_ss_kernel<TM, M>), grid, dim3(256), lds, st, x, dy, slab, p);                           \
+    hipLaunchKernelGGL((conv_wgrad_ss_kernel<TM, M, MASK>), grid, dim3(256), lds, st, x, dy, slab, p);                           \
   }
   if (math == 1) GCA_SS(1) else GCA_SS(2)
 #undef GCA_SS
@@ -634,7 +645,8 @@ bool wgrad_ts_ok(const gca_conv_geom* g, int tile, int math) {
     if (g->act_f16) return false;
     if (g->kd != 1 || g->kh != 3 || g->kw != 3 || g->sd != 1 || g->sh != 1 || g->sw != 1) return false;
     if (g->pd != 0 || g->ph != 1 || g->pw != 1) return false;
-    if (g->W % 4 != 0 || g->H < 2) return false;                  // zero padding = whole quads outside the row
+    if (g->H < 2) return false;
+    if (g->W % 4 != 0 && g->W > 16) return false;                 // whole quads outside the row, or ONE chunk per row with its tail masked
     return true;
   }
   if (tile != 11 && tile != 12) return false;
@@ -683,7 +695,8 @@ static int wgrad_ss_launch(const gca_conv_geom* g, int math, int splits, const f
   if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
   const size_t ring = (size_t)4 * PF * (2 + 3) * 1024;
   const size_t red = (size_t)2 * 9 * 16 * 64 * 4;
-  return launch_ss<1>(math, dim3((unsigned)nblk), ring > red ? ring : red, st, x, dy, slab, p);
+  if (g->W % 4) return launch_ss<1, true>(math, dim3((unsigned)nblk), ring > red ? ring : red, st, x, dy, slab, p);
+  return launch_ss<1, false>(math, dim3((unsigned)nblk), ring > red ? ring : red, st, x, dy, slab, p);
 }
 
 int wgrad_ts_launch(const gca_conv_geom* g, int tile, int math, int splits, const float* x, const float* dy, float* slab,

@@ -216,7 +216,7 @@ class ConvPlan:
                     cands.append((idx, max(1, min(units // 4, -(-nb // tiles)))))
         # the streaming (1,3,3) kernel (tile 13): units = (clip, plane, 16-column chunk); one wave per SIMD, so the block
         # count that fills the chip once (256) and its multiples are the candidates worth timing
-        if ((g.kd, g.kh, g.kw, g.sd, g.sh, g.sw, g.pd, g.ph, g.pw) == (1, 3, 3, 1, 1, 1, 0, 1, 1) and g.W % 4 == 0 and g.H >= 2
+        if ((g.kd, g.kh, g.kw, g.sd, g.sh, g.sw, g.pd, g.ph, g.pw) == (1, 3, 3, 1, 1, 1, 0, 1, 1) and (g.W % 4 == 0 or g.W <= 16) and g.H >= 2
                 and not g.act_f16):
             units = g.N * g.D * -(-g.W // 16)
             tiles = -(-M // 32) * -(-g.C // 32)
