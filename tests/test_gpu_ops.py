@@ -880,8 +880,6 @@ def test_conv_wgrad_streaming_temporal_kernel(ops, shape, K, kd, pd):
                 plan = ops.ConvPlan(N, C, D, Hh, W, K, (kd, 1, 1), 1, (pd, 0, 0), DEV, x_batch_stride=xin.stride(0) if view else 0)
                 plan.tuned = [True, True, True]
                 for tile in (11, 12):
-                    if tile == 12 and kd == 7:
-                        continue
                     for sp in sorted({1, 2, max(1, units // 8), max(1, units // 4)}):
                         plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = tile, sp
                         plan.refresh()
@@ -957,3 +955,30 @@ def test_conv_wgrad_streaming_spatial_kernel(ops, shape, K):
             assert plan.cfg(2)[3] & 255 != 13
     finally:
         ops.set_conv_math(default)
+
+
+@pytest.mark.parametrize('shape,K,kd,sd,pd', [
+    ((4, 48, 1, 4, 4), 40, 3, 1, 1),        # D = 1: only the centre tap meets data (layer4 of R(2+1)D-18)
+    ((3, 32, 2, 5, 5), 24, 3, 2, 1),        # D = 2, temporal stride 2 -> OD = 1: taps 1, 2
+    ((2, 32, 2, 4, 4), 32, 7, 1, 3),        # D = 2 under a 7-tap window: taps 2..4
+    ((2, 32, 3, 4, 4), 32, 3, 1, 1),        # nothing to drop
+    ((2, 32, 1, 4, 4), 32, 3, 1, 0 + 1),
+])
+def test_temporal_convs_drop_taps_that_only_meet_padding(ops, ctol, shape, K, kd, sd, pd):
+    """Forward / dgrad classes of (kd,1,1) convs leave out the taps that multiply zero padding for every output position
+    (conv_igemm_host.h build_classes); results against ATen, packed size shrinks accordingly."""
+    torch.manual_seed(kd + shape[2])
+    x = torch.randn(shape)
+    w = torch.randn(K, shape[1], kd, 1, 1) * 0.1
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, (sd, 1, 1), (pd, 0, 0))
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    plan = ops.ConvPlan(*shape, K, (kd, 1, 1), (sd, 1, 1), (pd, 0, 0), DEV)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    y, (ss, sq) = ops.conv_fwd(plan, xd, ops.conv_pack(plan, 0, wd), None, stats=True)
+    dx = ops.conv_dgrad(plan, dyd, ops.conv_pack(plan, 1, wd))
+    dw = torch.zeros_like(wd)
+    ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
+    assert rel_err(y, yr) < ctol and rel_err(dx, xr.grad) < ctol and rel_err(dw, wr.grad) < ctol
+    assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4

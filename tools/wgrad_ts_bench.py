@@ -52,8 +52,6 @@ def main():
         plan.g.tune_wgrad_math = 0
         units = N * (H * W // 16)
         for tile in (11, 12):
-            if tile == 12 and kd == 7:
-                continue
             tm = 2 if tile == 12 else 1
             tiles = -(-K // (32 * tm)) * -(-C // 32)
             for nb in (128, 256, 512, 1024, 2048):

@@ -650,7 +650,6 @@ bool wgrad_ts_ok(const gca_conv_geom* g, int tile, int math) {
     return true;
   }
   if (tile != 11 && tile != 12) return false;
-  if (tile == 12 && g->kd == 7) return false;                // (2 x 7 accumulator tiles per wave spill: not built)
   if (math != 1 && math != 2) return false;
   if (g->act_f16) return false;
   if (g->kh != 1 || g->kw != 1 || g->sd != 1 || g->sh != 1 || g->sw != 1 || g->ph != 0 || g->pw != 0) return false;
@@ -731,7 +730,7 @@ int wgrad_ts_launch(const gca_conv_geom* g, int tile, int math, int splits, cons
   const size_t red = (size_t)2 * tm * g->kd * 16 * 64 * 4;
   const size_t lds = ring > red ? ring : red;
   const dim3 grid((unsigned)nblk);
-  if (g->kd == 7) return launch_ts<7, 1>(math, grid, lds, st, x, dy, slab, p);
+  if (g->kd == 7) return tm == 2 ? launch_ts<7, 2>(math, grid, lds, st, x, dy, slab, p) : launch_ts<7, 1>(math, grid, lds, st, x, dy, slab, p);
   if (tm == 2) return launch_ts<3, 2>(math, grid, lds, st, x, dy, slab, p);
   return launch_ts<3, 1>(math, grid, lds, st, x, dy, slab, p);
 }

@@ -1,6 +1,7 @@
 // Host-side problem description shared by the forward / dgrad implicit-GEMM kernels (conv3d.hip: per-tap gathers;
 // conv3d_halo.hip: LDS halo tiles): problem classes, kernel parameter block, packed-weight geometry.
 #pragma once
+#include <algorithm>
 #include <vector>
 #include "conv_common.h"
 
@@ -89,6 +90,13 @@ inline void build_classes(const gca_conv_geom* g, int which, std::vector<ClassIn
       c.q[d] = od[d]; c.dm[d] = 1; c.dof[d] = 0; c.m[d] = sdim[d]; c.o[d] = -pdim[d];
     }
     c.srcC = g->C; c.M = g->K;
+    // Temporal convs on short clips: a tap a of dimension d meets real input for some output position only if
+    // p - (OD-1) s <= a <= D - 1 + p; the others multiply the zero padding for EVERY output (layer4 of R(2+1)D-18 runs
+    // (3,1,1) convs on D = 1: two of three taps).  Such taps are dropped from the class -- no MFMA work, no packed weights.
+    if (g->kh == 1 && g->kw == 1 && g->C > 4) {
+      const int amin = std::max(0, pdim[0] - (od[0] - 1) * sdim[0]), amax = std::min(kdim[0] - 1, in[0] - 1 + pdim[0]);
+      if (amin <= amax && (amin > 0 || amax < kdim[0] - 1)) { c.k0[0] = amin; c.dl0[0] = amin; c.na = amax - amin + 1; }
+    }
     finish(c);
     return;
   }
@@ -110,6 +118,13 @@ inline void build_classes(const gca_conv_geom* g, int which, std::vector<ClassIn
           c.dm[d] = sdim[d]; c.dof[d] = rho[d];
           c.m[d] = 1; c.o[d] = 0;
           if (cnt[d] == 0 || c.q[d] == 0) empty = true;
+        }
+        if (!empty && g->kh == 1 && g->kw == 1 && g->C > 4) {
+          // the same for the transposed problem: tap j of the class reads dY position q + dl0 - j, q in [0, c.q); taps that
+          // fall outside [0, OD) for every q are dropped
+          const int jmin = std::max(0, c.dl0[0] - (od[0] - 1)), jmax = std::min(cnt[0] - 1, c.dl0[0] + c.q[0] - 1);
+          if (jmin > jmax) empty = true;
+          else if (jmin > 0 || jmax < cnt[0] - 1) { c.k0[0] += sdim[0] * jmin; c.dl0[0] -= jmin; cnt[0] = jmax - jmin + 1; }
         }
         c.na = cnt[0]; c.nb = cnt[1]; c.nc = cnt[2];
         c.srcC = g->K; c.M = g->C;

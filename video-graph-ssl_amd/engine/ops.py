@@ -209,8 +209,6 @@ class ConvPlan:
         if (g.kh, g.kw, g.sd, g.sh, g.sw, g.ph, g.pw) == (1, 1, 1, 1, 1, 0, 0) and g.kd in (3, 7) and hw % 16 == 0 and not g.act_f16:
             units = g.N * (hw // 16)
             for idx, tm in ((11, 1), (12, 2)):
-                if idx == 12 and g.kd == 7:
-                    continue
                 tiles = -(-M // (32 * tm)) * -(-g.C // 32)
                 for nb in (256, 512, 1024):
                     cands.append((idx, max(1, min(units // 4, -(-nb // tiles)))))
