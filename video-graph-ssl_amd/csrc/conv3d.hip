@@ -1288,7 +1288,7 @@ int conv_math() {
 
 extern "C" {
 
-int gca_version(void) { return 13; }
+int gca_version(void) { return 14; }
 
 int gca_set_conv_math(int mode) {
   if (mode < 0 || mode > 2) return GCA_EINVAL;
