@@ -163,8 +163,23 @@ typedef struct {
   int32_t splits, accumulate;
   int32_t first_block, nblocks;     /* filled by gca_reduce_jobs_finalize_host */
 } gca_reduce_job;
-int gca_conv_wgrad_partial(const gca_conv_geom* g, const void* x, const void* dy, const int32_t* table, void* slabs,
-                           int32_t* out_splits, void* stream);
+int gca_conv_wgrad_partial(const gca_conv_geom* g, const void* x, const float* in_scale, const float* in_shift, const void* dy,
+                           const int32_t* table, void* slabs, int32_t* out_splits, void* stream);   /* in_scale / in_shift: see below; NULL = x as it is */
+
+/* BatchNorm + ReLU of the PRODUCING layer applied where the consumer reads its input, so the normalised tensor
+ * z = relu(y * scale[c] + shift[c]) of a conv -> BN -> ReLU -> conv link (resnet2p1d.py:66-85: bn1_s -> conv1_t, bn1_t -> conv2_s,
+ * bn2_s -> conv2_t; :252-253 the stem) is never written or read: 2 of the 7 tensor passes of such a BatchNorm.
+ * gca_conv_fwd_xf / gca_conv_wgrad_xf take the PRE-activation tensor y as `x` plus (scale, shift) of gca_bn_finalize
+ * (arrays padded to a multiple of 16 floats + 16) and compute exactly what gca_conv_fwd / gca_conv_wgrad compute on z
+ * (zero padding pads z).  Only launch configurations that pass their input through registers can do it:
+ * gca_conv_xf_ok(g) = 1 when, under the tune_* fields in force, the forward runs on the LDS-halo kernels and the weight
+ * gradient on the streaming temporal kernels (fp32 storage, split-product arithmetic); otherwise these entries return
+ * GCA_EINVAL and the caller materialises z with gca_bn_apply. */
+int gca_conv_xf_ok(const gca_conv_geom* g);
+int gca_conv_fwd_xf(const gca_conv_geom* g, const void* x, const float* in_scale, const float* in_shift, const float* wpack,
+                    const int32_t* table, const float* bias, void* y, float* stat_sum, float* stat_sq, void* ws, void* stream);
+int gca_conv_wgrad_xf(const gca_conv_geom* g, const void* x, const float* in_scale, const float* in_shift, const void* dy,
+                      const int32_t* table, float* dw, int accumulate, void* ws, void* stream);
 int64_t gca_reduce_jobs_finalize_host(gca_reduce_job* jobs, int64_t njobs);
 int gca_splitk_reduce_batched(const gca_reduce_job* jobs_dev, int64_t njobs, int64_t total_blocks, void* stream);
 /* Launch shape the wgrad kernel will use for g: out4 = {tile rows (output channels), tile columns (C*taps),

@@ -982,3 +982,70 @@ def test_temporal_convs_drop_taps_that_only_meet_padding(ops, ctol, shape, K, kd
     ops.conv_wgrad(plan, xd, dyd, dw, accumulate=True)
     assert rel_err(y, yr) < ctol and rel_err(dx, xr.grad) < ctol and rel_err(dw, wr.grad) < ctol
     assert rel_err(ss.sum(1), yr.detach().sum((0, 2, 3, 4))) < 1e-4
+
+
+@pytest.mark.parametrize('shape,K,kd,pd', [
+    ((3, 40, 6, 4, 8), 48, 3, 1),        # residual-block kind; C = 2.5 chunks of 16 (channel tail), K tile tail
+    ((2, 110, 9, 4, 4), 64, 7, 3),       # the stem's temporal conv kind
+])
+def test_conv_consumes_producer_batchnorm_relu_on_the_fly(ops, shape, K, kd, pd):
+    """gca_conv_fwd_xf / gca_conv_wgrad_xf: a conv that reads its producer's PRE-activation tensor y and applies
+    relu(y * scale[c] + shift[c]) where it stages its input (LDS-halo forward, streaming weight gradient) against the same conv
+    on the materialised tensor z (gca_bn_apply) -- same kernels, same products: bit for bit -- and against ATen on z.  Negative
+    shifts make whole regions of z zero; the conv's zero padding must pad z (not relu(shift))."""
+    torch.manual_seed(31)
+    N, C, D, Hh, W = shape
+    y_in = torch.randn(shape, device=DEV)
+    gam = torch.rand(C, device=DEV) + 0.5
+    bet = torch.randn(C, device=DEV) + 0.7                         # mostly positive shifts: relu(shift) != 0 in the padding
+    ss, sq = ops.bn_stats(y_in, N, C, D * Hh * W)
+    rm, rv, nb = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    mean, invstd, scale, shift = ops.bn_finalize(ss, sq, N * D * Hh * W, gam, bet, 1e-5, 0.1, rm, rv, nb)
+    z = ops.bn_apply(y_in, scale, shift, None, True, N, C, D * Hh * W)
+    w = torch.randn(K, C, kd, 1, 1, device=DEV) * 0.1
+    zr, wr = z.detach().cpu().double().requires_grad_(True), w.cpu().double().requires_grad_(True)
+    outr = F.conv3d(zr, wr, None, 1, (pd, 0, 0))
+    dy = torch.randn(outr.shape)
+    outr.backward(dy.double())
+    default = ops.get_conv_math()
+    try:
+        for mode, tol in (('bf16x6', 1e-5), ('bf16x3', 5e-5)):
+            ops.set_conv_math(mode)
+            plan = ops.ConvPlan(N, C, D, Hh, W, K, (kd, 1, 1), 1, (pd, 0, 0), DEV)
+            plan.tuned = [True, True, True]
+            assert not ops.conv_xf_ok(plan)                                     # heuristic shapes: gather kernels / conv_wgrad_kernel
+            # a halo box that fits: bd x bh x bw = 128 positions
+            box = None
+            for bd in (1, 2, 4, 8):
+                for bh in (1, 2, 4, 8):
+                    bw = 128 // (bd * bh)
+                    if bw >= 1 and bd * bh * bw == 128 and bd <= 2 * D and bh <= 2 * Hh and bw <= 2 * W and (bd + kd - 1) * bh * bw <= 384:
+                        box = box or (bd, bh, bw)
+            plan.g.tune_fwd_bm, plan.g.tune_fwd_box = 64 | 2048, box[0] | (box[1] << 8) | (box[2] << 16)
+            plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = 11, 2
+            plan.refresh()
+            assert (plan.cfg(0)[3] >> 14) & 1 and plan.cfg(2)[3] & 255 == 11
+            assert ops.conv_xf_ok(plan)
+            wp = ops.conv_pack(plan, 0, w)
+            o1, (s1, q1) = ops.conv_fwd(plan, z, wp, None, stats=True)
+            o2, (s2, q2) = ops.conv_fwd_xf(plan, y_in, scale, shift, wp, stats=True)
+            assert torch.equal(o1, o2) and torch.equal(s1, s2) and torch.equal(q1, q2)
+            assert rel_err(o2, outr) < tol
+            dyd = dy.to(DEV)
+            g1, g2 = torch.zeros_like(w), torch.zeros_like(w)
+            ops.conv_wgrad(plan, z, dyd, g1, accumulate=True)
+            ops.conv_wgrad(plan, y_in, dyd, g2, accumulate=True, xf=(scale, shift))
+            assert torch.equal(g1, g2)
+            assert rel_err(g2, wr.grad) < tol
+            # through the collector (one batched reduce) as the trainers run it
+            d = ops.DeferredReduce()
+            g3 = torch.zeros_like(w)
+            ops.DEFER[0] = d
+            try:
+                ops.conv_wgrad(plan, y_in, dyd, g3, accumulate=True, xf=(scale, shift))
+                d.flush()
+            finally:
+                ops.DEFER[0] = None
+            assert torch.equal(g3, g2)
+    finally:
+        ops.set_conv_math(default)

@@ -971,6 +971,7 @@ inline bool stem_geometry(const gca_conv_geom* g, const IgemmParams& p, int math
 
 // halo geometry of class c tiled by boxes (bd, bh, bw); false when the class / box cannot run on the halo kernels
 inline bool halo_geometry(const ClassInfo& c, const IgemmParams& p, int bd, int bh, int bw, int math, HaloParams& hp) {
+  hp.in_scale = nullptr; hp.in_shift = nullptr;
   if (c.ntaps < 1 || c.ntaps > 64 || c.srcC < 8) return false;
   if (!is_pow2(bd) || !is_pow2(bh) || !is_pow2(bw)) return false;
   const int bn = bd * bh * bw;
@@ -1208,9 +1209,10 @@ int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack,
 // One class on the LDS-halo kernels.  `tapdelta` = the 64-entry tap-delta table that follows the class's gather rows.
 int run_class_halo(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& cf, const float* src, const float* apack,
                    const int2* table, const float* bias, float* dst, float* psum, float* psq, float* slab, IgemmParams p,
-                   hipStream_t st) {
+                   hipStream_t st, const float* in_scale = nullptr, const float* in_shift = nullptr) {
   HaloParams hp;
   if (!halo_geometry(c, p, cf.bd, cf.bh, cf.bw, cf.math, hp)) return GCA_EINVAL;
+  hp.in_scale = in_scale; hp.in_shift = in_shift;
   if (cf.splits > 1 && !slab) return GCA_EINVAL;
   hp.g.splits = cf.splits; hp.g.kt_per_split = cf.kt_per_split;
   hp.chunks_per_split = cf.kt_per_split;
@@ -1515,6 +1517,36 @@ int gca_conv_fwd(const gca_conv_geom* g, const void* x_, const float* wpack, con
                           reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
   return run_class(cf, fast_of(c.ntaps), x, wpack, reinterpret_cast<const int2*>(table), bias,
                    y, stat_sum, stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
+}
+
+int gca_conv_xf_ok(const gca_conv_geom* g) {
+  if (!geom_ok(g) || g->act_f16) return 0;
+  std::vector<ClassInfo> cls;
+  build_classes(g, 0, cls);
+  IgemmParams p{};
+  class_params(g, 0, cls[0], p);
+  const IgemmCfg cf = cfg_for(g, 0, cls[0], p, 1);
+  if (cf.halo != 1 || cf.math == 3) return 0;
+  const int wm = resolve_math(g->tune_wgrad_math, 0);
+  return g->tune_wgrad_tile >= 11 && g->tune_wgrad_tile <= 12 && wgrad_ts_ok(g, g->tune_wgrad_tile, wm) ? 1 : 0;
+}
+
+int gca_conv_fwd_xf(const gca_conv_geom* g, const void* x_, const float* in_scale, const float* in_shift, const float* wpack,
+                    const int32_t* table, const float* bias, void* y_, float* stat_sum, float* stat_sq, void* ws, void* stream) {
+  const float* x = reinterpret_cast<const float*>(x_);
+  float* y = reinterpret_cast<float*>(y_);
+  if (!geom_ok(g) || g->act_f16 || !x || !in_scale || !in_shift || !wpack || !table || !y) return GCA_EINVAL;
+  if ((stat_sum == nullptr) != (stat_sq == nullptr)) return GCA_EINVAL;
+  std::vector<ClassInfo> cls;
+  build_classes(g, 0, cls);
+  const ClassInfo& c = cls[0];
+  IgemmParams p{};
+  class_params(g, 0, c, p);
+  p.accumulate = 0;
+  const IgemmCfg cf = cfg_for(g, 0, c, p, 1);
+  if (cf.halo != 1) return GCA_EINVAL;                 // only the LDS-halo kernels stage their input through registers
+  return run_class_halo(g, c, cf, x, wpack, reinterpret_cast<const int2*>(table), bias, y, stat_sum, stat_sq,
+                        reinterpret_cast<float*>(ws), p, (hipStream_t)stream, in_scale, in_shift);
 }
 
 int gca_conv_dgrad(const gca_conv_geom* g, const void* dy_, const float* wpack, const int32_t* table,

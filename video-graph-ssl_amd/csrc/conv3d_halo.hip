@@ -113,8 +113,10 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
 
   float hreg[HR][8];
   uint4 areg[A_PC];
+  int hchunk = 0;               // chunk whose halo sits in hreg (for the input transform)
   auto halo_issue = [&](int c) __attribute__((always_inline)) {
     const int c0 = c * 16;
+    hchunk = c;
 #pragma unroll
     for (int r = 0; r < HR; ++r)
 #pragma unroll
@@ -125,6 +127,25 @@ __global__ __launch_bounds__(256, (TM * TN <= 6 ? 2 : 1)) void conv_halo_kernel(
       }
   };
   auto halo_store = [&]() __attribute__((always_inline)) {
+    if constexpr (!F16) {
+      if (hp.in_scale) {
+        // relu(x * scale[c] + shift[c]) on the staged values (the producer's BatchNorm + ReLU, bn.hip bn_apply_kernel's
+        // arithmetic); positions outside the tensor and channels past the end stay exactly zero (the padding pads the
+        // TRANSFORMED tensor; a garbage scale must not turn a zero-weight product into NaN)
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+          const int hu = __builtin_amdgcn_readfirstlane(hhalf[r]);          // (wave-uniform: 384 = 6 waves of tasks per half)
+          const int cb = hchunk * 16 + 8 * hu;
+          const bool okp = hvoff[r] != 0xffffffffu;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float sc = hp.in_scale[cb + j], sf = hp.in_shift[cb + j];
+            const float v = fmaxf(hreg[r][j] * sc + sf, 0.f);
+            hreg[r][j] = (okp && cb + j < p.SC) ? v : 0.f;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int r = 0; r < HR; ++r) {
       unsigned char* d = Hs + hwoff[r];

@@ -787,7 +787,7 @@ int gca_conv_wgrad_cfg(const gca_conv_geom* g, int32_t* out4) {
 
 // the split-K kernel of `g` into `slab` (gca_conv_wgrad_ws_bytes); -> splits (> 0) or a negative status
 static int wgrad_partial_launch(const gca_conv_geom* g, const void* x_, const void* dy_, const int32_t* table, void* ws,
-                                hipStream_t st) {
+                                hipStream_t st, const float* in_scale = nullptr, const float* in_shift = nullptr) {
   const float* x = reinterpret_cast<const float*>(x_);      // opaque to the host side: the kernels index in bytes
   const float* dy = reinterpret_cast<const float*>(dy_);
   if (!geom_ok(g) || !x || !dy || !table || !ws) return GCA_EINVAL;
@@ -804,9 +804,10 @@ static int wgrad_partial_launch(const gca_conv_geom* g, const void* x_, const vo
     // 16-byte DMA pieces; rows of the (1,3,3) kernel start at arbitrary columns anyway, so only dword alignment matters there
     if (pl.ts != 13 && (((uintptr_t)x % 16) || ((uintptr_t)dy % 16))) return GCA_EINVAL;
     if (((uintptr_t)x % 4) || ((uintptr_t)dy % 4)) return GCA_EINVAL;
-    rc = wgrad_ts_launch(g, pl.ts, p.math, p.splits, x, dy, slab, st);
+    rc = wgrad_ts_launch(g, pl.ts, p.math, p.splits, x, dy, slab, st, in_scale, in_shift);
     return rc ? rc : p.splits;
   }
+  if (in_scale) return GCA_EINVAL;                       // only the streaming kernels transform x on the fly (gca_conv_xf_ok)
   const int av = !pl.avec || ((uintptr_t)dy % 16) ? 0 : (pl.bvec && ((uintptr_t)x % 16) == 0 ? 2 : 1);
   if (pl.fast == 1) rc = launch_shape<1>(pl.shape, av, grid, st, x, dy, t, slab, p);
   else if (pl.fast == 2) rc = launch_shape<2>(pl.shape, av, grid, st, x, dy, t, slab, p);
@@ -818,9 +819,14 @@ static int wgrad_partial_launch(const gca_conv_geom* g, const void* x_, const vo
 
 int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, const int32_t* table,
                    float* dw, int accumulate, void* ws, void* stream) {
-  if (!dw) return GCA_EINVAL;
+  return gca_conv_wgrad_xf(g, x_, nullptr, nullptr, dy_, table, dw, accumulate, ws, stream);
+}
+
+int gca_conv_wgrad_xf(const gca_conv_geom* g, const void* x_, const float* in_scale, const float* in_shift, const void* dy_,
+                      const int32_t* table, float* dw, int accumulate, void* ws, void* stream) {
+  if (!dw || ((in_scale == nullptr) != (in_shift == nullptr))) return GCA_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  const int splits = wgrad_partial_launch(g, x_, dy_, table, ws, st);
+  const int splits = wgrad_partial_launch(g, x_, dy_, table, ws, st, in_scale, in_shift);
   if (splits < 0) return splits;
   float* slab = reinterpret_cast<float*>(ws);
   const long long n = (long long)g->K * g->C * taps(g);
@@ -833,10 +839,10 @@ int gca_conv_wgrad(const gca_conv_geom* g, const void* x_, const void* dy_, cons
   return gca_launch_status();
 }
 
-int gca_conv_wgrad_partial(const gca_conv_geom* g, const void* x, const void* dy, const int32_t* table, void* slabs,
-                           int32_t* out_splits, void* stream) {
-  if (!out_splits) return GCA_EINVAL;
-  const int splits = wgrad_partial_launch(g, x, dy, table, slabs, (hipStream_t)stream);
+int gca_conv_wgrad_partial(const gca_conv_geom* g, const void* x, const float* in_scale, const float* in_shift, const void* dy,
+                           const int32_t* table, void* slabs, int32_t* out_splits, void* stream) {
+  if (!out_splits || ((in_scale == nullptr) != (in_shift == nullptr))) return GCA_EINVAL;
+  const int splits = wgrad_partial_launch(g, x, dy, table, slabs, (hipStream_t)stream, in_scale, in_shift);
   if (splits < 0) return splits;
   *out_splits = splits;
   return GCA_OK;

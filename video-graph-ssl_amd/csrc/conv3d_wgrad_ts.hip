@@ -38,6 +38,10 @@ struct TsParams {
   unsigned x_nstride, dy_nstride;   // elements between clips
   unsigned x_bytes, dy_bytes, slab_bytes;
   gca_magic m_chunks;
+  // optional input transform: x stands for relu(x * in_scale[c] + in_shift[c]) (the producer's BatchNorm + ReLU, never
+  // materialised); a lane's fragment row IS a channel, so the pair sits in two registers for the whole kernel
+  const float* in_scale;
+  const float* in_shift;
 };
 
 constexpr int PF = 4;            // ring depth (steps of DMA in flight: PF - 1 behind the one being read)
@@ -161,6 +165,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_ts_kernel(const float* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][a][r] = 0.f;
 
+  const bool xf = p.in_scale != nullptr;
+  const float xsc = xf ? p.in_scale[min(c0 + ll, p.C - 1)] : 1.f, xsh = xf ? p.in_shift[min(c0 + ll, p.C - 1)] : 0.f;
+  auto xform = [&](float4& v) __attribute__((always_inline)) {      // bn.hip bn_apply_kernel's arithmetic
+    v.x = fmaxf(v.x * xsc + xsh, 0.f); v.y = fmaxf(v.y * xsc + xsh, 0.f);
+    v.z = fmaxf(v.z * xsc + xsh, 0.f); v.w = fmaxf(v.w * xsc + xsh, 0.f);
+  };
   Frag win[KD];                    // B fragments: plane e sits in slot e % KD
   Frag af[TM], afn[TM];            // A fragments of this step / the next
   float4 ra[TM][2], rb[2];         // raw fp32 fragments of the next step
@@ -202,6 +212,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ts_kernel(const float* __restr
     issue_step();                                           // step PF -> stage 0 (just read)
 #pragma unroll
     for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], af[i]);
+    if (xf) { xform(rb[0]); xform(rb[1]); }
     split8(rb[0], rb[1], win[0]);
 
     int j = 0, rstage = 1;
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ts_kernel(const float* __restr
           if (a == (KD > 3 ? 2 : 1)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             issue_step();
+            if (xf) { xform(rb[0]); xform(rb[1]); }
             split8(rb[0], rb[1], win[(b + 1) % KD]);
 #pragma unroll
             for (int i = 0; i < TM; ++i) split8(ra[i][0], ra[i][1], afn[i]);
@@ -699,8 +711,8 @@ static int wgrad_ss_launch(const gca_conv_geom* g, int math, int splits, const f
 }
 
 int wgrad_ts_launch(const gca_conv_geom* g, int tile, int math, int splits, const float* x, const float* dy, float* slab,
-                    hipStream_t st) {
-  if (tile == 13) return wgrad_ss_launch(g, math, splits, x, dy, slab, st);
+                    hipStream_t st, const float* in_scale, const float* in_shift) {
+  if (tile == 13) return in_scale ? GCA_EINVAL : wgrad_ss_launch(g, math, splits, x, dy, slab, st);
   const int tm = tile == 12 ? 2 : 1;
   TsParams p;
   p.K = g->K; p.C = g->C; p.D = g->D; p.OD = g->OD; p.HW = g->H * g->W; p.pd = g->pd;
@@ -724,6 +736,7 @@ int wgrad_ts_launch(const gca_conv_geom* g, int tile, int math, int splits, cons
   p.dy_bytes = yb > 0xfffff000LL ? 0xfffff000u : (unsigned)yb;
   p.slab_bytes = sb > 0xfffff000LL ? 0xfffff000u : (unsigned)sb;
   p.m_chunks = gca_make_magic((unsigned)p.chunks);
+  p.in_scale = in_scale; p.in_shift = in_shift;
   const long long nblk = (long long)p.tilesM * p.tilesC * p.splits;
   if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
   const size_t ring = (size_t)4 * PF * (2 * tm + 2) * 1024;

@@ -112,7 +112,7 @@ inline int taps(const gca_conv_geom* g) { return g->kd * g->kh * g->kw; }
 bool wgrad_ts_ok(const gca_conv_geom* g, int tile, int math);
 int wgrad_ts_splits(const gca_conv_geom* g, int tile, int want);
 int wgrad_ts_launch(const gca_conv_geom* g, int tile, int math, int splits, const float* x, const float* dy, float* slab,
-                    hipStream_t st);
+                    hipStream_t st, const float* in_scale = nullptr, const float* in_shift = nullptr);
 inline bool unit_stride(const gca_conv_geom* g) { return g->sd == 1 && g->sh == 1 && g->sw == 1; }
 
 

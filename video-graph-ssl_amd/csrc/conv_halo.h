@@ -18,6 +18,11 @@ struct HaloParams {
   int Mrows;             // rows of one packed A step
   unsigned cs_bytes;     // channel stride of the gathered tensor (bytes)
   unsigned pack_bytes;   // extent of this class's packed weights
+  // optional input transform (forward, fp32 storage): the conv consumes relu(x * in_scale[c] + in_shift[c]) -- the BatchNorm +
+  // ReLU of the producing layer, applied where the halo is staged (once per staged element), so that tensor is never
+  // written or read.  Zero padding applies to the TRANSFORMED tensor.  Arrays hold >= 16 * nchunks floats.
+  const float* in_scale;
+  const float* in_shift;
 };
 
 struct HaloCfg {

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import ops
 from . import tape as _tape
-from .tape import Var
+from .tape import LazyVar, Var
 
 
 GRAD_LOG = None        # a list while a trainer maps parameters to backward closures: (closure index, parameter)
@@ -209,6 +209,24 @@ def _stored(x):
     return x
 
 
+# GCA_LAZY_BN=0: every BatchNorm writes its normalised tensor (A/B runs)
+import os as _os
+LAZY_BN = _os.environ.get('GCA_LAZY_BN', '1') != '0'
+
+
+def _conv_input(conv, xv):
+    """-> (plan, x, xf): what a conv reads.  A LazyVar producer (conv -> BN -> ReLU not yet written) is consumed as (y, (scale,
+    shift)) when this conv's pinned launch shapes can apply the BatchNorm + ReLU while staging (ops.conv_xf_ok: forward on an
+    LDS-halo kernel, weight gradient on a streaming kernel; resnet2p1d.py:66-85's bn1_s -> conv1_t, bn1_t -> conv2_s,
+    bn2_s -> conv2_t and the stem, s3d_1.py:61-68's conv_s -> conv_t); otherwise its `.t` materialises z."""
+    if isinstance(xv, LazyVar) and not xv.materialized and LAZY_BN:
+        plan = conv.plan(xv.y)
+        if ops.conv_xf_ok(plan):
+            return plan, xv.y, (xv.scale, xv.shift)
+    x = _stored(xv.t)
+    return conv.plan(x), x, None
+
+
 def f_seq(tape, module, xv):
     """Run a container: modules with their own ``fwd`` (blocks, graph-wrapped modules), max pools and
     plain nn.Sequential chains of those."""
@@ -244,24 +262,34 @@ def f_concat(tape, buf, branch_vars, offsets):
 def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
     """z = [relu]( BN(conv(x)) [+ residual] ).  Training-mode BN takes its batch statistics from the
     conv epilogue (no extra pass over y).  Follows resnet2p1d.py:66-85 / s3d_1.py:43-47,61-68.
-    `out`: optional channel-slice view of a wider buffer to receive z (Inception concat)."""
-    x = _stored(xv.t)
-    plan = conv.plan(x)
+    `out`: optional channel-slice view of a wider buffer to receive z (Inception concat).
+    A plain conv -> BN -> ReLU unit (no residual, no slice) returns a LazyVar: z is written only if some consumer asks for it."""
+    plan, x, xf = _conv_input(conv, xv)
     N, K, OD, OH, OW = plan.out_shape
     SP = OD * OH * OW
     wp = conv.packed(plan, 0)
     train = bn.training
+    lazy = LAZY_BN and train and relu and residual is None and out is None and x.dtype is torch.float32
+    z = None
     if train:
-        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
-        z, mean, invstd, scale, shift = ops.bn_train_fwd(ss, sq, N * SP, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,
-                                                         bn.running_mean, bn.running_var, bn.num_batches_tracked, y,
-                                                         None if residual is None else residual.t, relu, N, K, SP, out=out)
+        if xf is not None:
+            y, (ss, sq) = ops.conv_fwd_xf(plan, x, xf[0], xf[1], wp, stats=True)
+        else:
+            y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
+        if lazy:
+            mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
+        else:
+            z, mean, invstd, scale, shift = ops.bn_train_fwd(ss, sq, N * SP, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,
+                                                             bn.running_mean, bn.running_var, bn.num_batches_tracked, y,
+                                                             None if residual is None else residual.t, relu, N, K, SP, out=out)
     else:
+        if xf is not None:                   # (a training-mode producer in front of an eval-mode unit: take its tensor)
+            x, xf = _stored(xv.t), None
         y = ops.conv_fwd(plan, x, wp, None, w_raw=conv.weight.data)
         mean = invstd = None
         scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
         z = ops.bn_apply(y, scale, shift, None if residual is None else residual.t, relu, N, K, SP, out=out)
-    zv = Var(z, tape.recording)
+    zv = LazyVar(y, scale, shift, tape.recording) if lazy else Var(z, tape.recording)
     if tape.recording:
         if not train:
             raise NotImplementedError('backward through eval-mode BatchNorm is not on the pre-training path')
@@ -278,7 +306,7 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
             if DEBUG_GRADS is not None:          # diagnostics only: gradient wrt the conv output, per BN module
                 DEBUG_GRADS[id(bn)] = (zv.grad.clone(), dy.clone())
             zv.grad = None
-            ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
+            ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True, xf=xf)
             if xv.needs_grad:
                 buf, acc = xv.grad_buffer()
                 ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc, w_raw=conv.weight.data)
@@ -375,15 +403,19 @@ def f_conv_bn_relu_maxpool(tape, conv, bn, pool, xv):
     """maxpool(relu(BN(conv(x)))) with the BN+ReLU evaluated inside the pooling kernel: the normalised tensor (the
     largest activation of the R(2+1)D / 3D-ResNet stems, resnet2p1d.py:252-255, resnet.py:176-179) is never written.
     Backward: pool gather -> BN backward with the ReLU mask recomputed from the conv output -> wgrad / dgrad."""
-    x = _stored(xv.t)
-    plan = conv.plan(x)
+    plan, x, xf = _conv_input(conv, xv)
     N, K, OD, OH, OW = plan.out_shape
     SP = OD * OH * OW
     wp = conv.packed(plan, 0)
     if bn.training:
-        y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
+        if xf is not None:
+            y, (ss, sq) = ops.conv_fwd_xf(plan, x, xf[0], xf[1], wp, stats=True)
+        else:
+            y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
         mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
     else:
+        if xf is not None:
+            x, xf = _stored(xv.t), None
         y = ops.conv_fwd(plan, x, wp, None, w_raw=conv.weight.data)
         mean = invstd = None
         scale, shift = ops.bn_fold_eval(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
@@ -400,7 +432,7 @@ def f_conv_bn_relu_maxpool(tape, conv, bn, pool, xv):
             dy = ops.bn_bwd(dz, None, y, bn.weight.data, mean, invstd, 2, N, K, SP, _grad_of(bn.weight), _grad_of(bn.bias),
                             None, False, scale, shift)
             del dz
-            ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True)
+            ops.conv_wgrad(plan, x, dy, _grad_of(conv.weight), accumulate=True, xf=xf)
             if xv.needs_grad:
                 buf, acc = xv.grad_buffer()
                 ops.conv_dgrad(plan, dy, conv.packed(plan, 1), buf, acc, w_raw=conv.weight.data)

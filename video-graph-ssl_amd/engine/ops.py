@@ -477,6 +477,25 @@ def conv_fwd(plan, x, wpack, bias=None, stats=False, w_raw=None):
     return (y, (ss, sq)) if stats else y
 
 
+def conv_xf_ok(plan):
+    """True when, under the launch shapes pinned in `plan`, the conv can consume relu(y*scale+shift) of its PRODUCER on the
+    fly (forward on an LDS-halo kernel, weight gradient on a streaming kernel): gca_conv_xf_ok."""
+    return plan.tuned[0] and plan.tuned[2] and plan.g.x_batch_stride == 0 and bool(H.lib.gca_conv_xf_ok(plan.gp))
+
+
+def conv_fwd_xf(plan, y_in, scale, shift, wpack, stats=False):
+    """conv_fwd on z = relu(y_in * scale[c] + shift[c]) without materialising z (scale / shift: padded rows of bn_finalize)."""
+    y = torch.empty(plan.out_shape, dtype=F32, device=y_in.device)
+    ss = sq = None
+    if stats:
+        ss = torch.empty((plan.g.K, plan.parts), dtype=F32, device=y_in.device)
+        sq = torch.empty((plan.g.K, plan.parts), dtype=F32, device=y_in.device)
+    ws = WS.get(plan.fwd_ws, y_in.device) if plan.fwd_ws else None
+    H.call('gca_conv_fwd_xf', plan.gp, ptr(y_in), ptr(scale), ptr(shift), ptr(wpack), ptr(plan.table(0)), None, ptr(y), ptr(ss),
+           ptr(sq), ptr(ws), stream())
+    return (y, (ss, sq)) if stats else y
+
+
 def _conv_dgrad_launch(plan, dy, wpack_t, dx, accumulate):
     ws = WS.get(plan.dgrad_ws, dy.device) if plan.dgrad_ws else None
     H.call('gca_conv_dgrad', plan.gp, _act(plan, dy), ptr(wpack_t), ptr(plan.table(1)), _act(plan, dx), int(accumulate), ptr(ws),
@@ -521,13 +540,13 @@ class DeferredReduce(object):
             b = self.slabs[key] = torch.empty(max(int(plan.wgrad_ws), 16), dtype=torch.uint8, device=dw.device)
         return b
 
-    def add(self, plan, x, dy, dw, accumulate):
+    def add(self, plan, x, dy, dw, accumulate, xf=None):
         if any(j[1].data_ptr() == dw.data_ptr() for j in self.pending):
             self.flush()                                   # a weight used twice (SimSiam's two views): keep the += order, no race
         slab = self.slab_for(dw, plan)
         splits = C.c_int32(0)
-        H.call('gca_conv_wgrad_partial', plan.gp, _act(plan, x), _act(plan, dy), ptr(plan.table(2)), slab.data_ptr(),
-               C.addressof(splits), stream())
+        H.call('gca_conv_wgrad_partial', plan.gp, _act(plan, x), ptr(xf[0]) if xf else None, ptr(xf[1]) if xf else None,
+               _act(plan, dy), ptr(plan.table(2)), slab.data_ptr(), C.addressof(splits), stream())
         self.pending.append((slab, dw, dw.numel(), int(splits.value), int(bool(accumulate))))
 
     def flush(self):
@@ -556,13 +575,22 @@ class DeferredReduce(object):
 DEFER = [None]
 
 
-def conv_wgrad(plan, x, dy, dw, accumulate=True):
+def conv_wgrad(plan, x, dy, dw, accumulate=True, xf=None):
+    """xf = (scale, shift): `x` is the producer's PRE-activation tensor, the gradient is taken against
+    relu(x * scale[c] + shift[c]) (gca_conv_wgrad_xf; only where conv_xf_ok(plan))."""
     if not plan.tuned[2]:
+        if xf is not None:
+            raise RuntimeError('conv_wgrad(xf=...) needs a tuned plan (conv_xf_ok)')
         scratch = torch.empty_like(dw)
         plan.tune(2, lambda: _conv_wgrad_launch(plan, x, dy, scratch, False))
     d = DEFER[0]
     if d is not None and dw.is_contiguous():
-        d.add(plan, x, dy, dw, accumulate)
+        d.add(plan, x, dy, dw, accumulate, xf)
+        return dw
+    if xf is not None:
+        ws = WS.get(plan.wgrad_ws, x.device)
+        H.call('gca_conv_wgrad_xf', plan.gp, _act(plan, x), ptr(xf[0]), ptr(xf[1]), _act(plan, dy), ptr(plan.table(2)), ptr(dw),
+               int(accumulate), ptr(ws), stream())
         return dw
     _conv_wgrad_launch(plan, x, dy, dw, accumulate)
     return dw
@@ -584,11 +612,14 @@ def bn_stats(x, N, Cc, SP):
 def bn_finalize(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt):
     """-> (save_mean, save_invstd, scale, shift); running stats updated in place."""
     Cc, P = ss.shape
-    out = torch.empty((4, Cc), dtype=F32, device=ss.device)
+    # rows padded to a multiple of 16 + 16 floats (zeros): a consumer that applies (scale, shift) while it stages its input
+    # (conv_fwd_xf) reads whole 16-channel chunks
+    Cp = -(-Cc // 16) * 16 + 16
+    out = torch.zeros((4, Cp), dtype=F32, device=ss.device)
     H.call('gca_bn_finalize', ptr(ss), ptr(sq), P, Cc, float(count), ptr(gamma), ptr(beta), float(eps),
            float(momentum), ptr(rmean), ptr(rvar), ptr(nbt), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
            stream())
-    return out[0], out[1], out[2], out[3]
+    return out[0][:Cc], out[1][:Cc], out[2][:Cc], out[3][:Cc]
 
 
 def bn_train_fwd(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt, x, residual, relu, N, Cc, SP, out=None):

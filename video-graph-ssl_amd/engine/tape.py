@@ -33,6 +33,36 @@ class Var:
             ops.axpy(self.grad, g, 1.0)
 
 
+class LazyVar(Var):
+    """z = relu(y * scale[c] + shift[c]) -- the output of a conv -> BatchNorm -> ReLU unit -- NOT yet written.  A consumer that
+    can apply the BatchNorm + ReLU where it reads its input (engine.layers: convs on the LDS-halo / streaming kernels) takes
+    (y, scale, shift) and z never exists; any other consumer reads `.t`, which materialises z once (gca_bn_apply: what the
+    producer would have launched anyway)."""
+    __slots__ = ('y', 'scale', 'shift', '_z')
+
+    def __init__(self, y, scale, shift, needs_grad=False):
+        self.y, self.scale, self.shift, self._z = y, scale, shift, None
+        self.grad = None
+        self.needs_grad = needs_grad
+
+    @property
+    def t(self):
+        if self._z is None:
+            N, Cc = self.y.shape[0], self.y.shape[1]
+            self._z = ops.bn_apply(self.y, self.scale, self.shift, None, True, N, Cc, self.y[0, 0].numel())
+        return self._z
+
+    @property
+    def materialized(self):
+        return self._z is not None
+
+    def grad_buffer(self):
+        if self.grad is None:
+            self.grad = torch.empty_like(self.y)
+            return self.grad, False
+        return self.grad, True
+
+
 CURRENT = [-1]        # index of the closure being run by Tape.backward (read by the gradient log of engine/layers.py)
 
 
