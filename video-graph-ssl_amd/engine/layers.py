@@ -212,6 +212,7 @@ def _stored(x):
 # GCA_LAZY_BN=0: every BatchNorm writes its normalised tensor (A/B runs)
 import os as _os
 LAZY_BN = _os.environ.get('GCA_LAZY_BN', '1') != '0'
+BN_SMALL_ELEMS = 32768      # bn.hip: N*SP at or below this runs finalize + apply as ONE launch
 
 
 def _conv_input(conv, xv):
@@ -269,7 +270,10 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
     SP = OD * OH * OW
     wp = conv.packed(plan, 0)
     train = bn.training
-    lazy = LAZY_BN and train and relu and residual is None and out is None and x.dtype is torch.float32
+    # (small maps keep the one-launch finalize + apply kernel of gca_bn_train_fwd: deferring their apply would ADD a launch,
+    # and their consumers run on the gather kernels anyway)
+    lazy = (LAZY_BN and train and relu and residual is None and out is None and x.dtype is torch.float32
+            and N * SP > BN_SMALL_ELEMS)
     z = None
     if train:
         if xf is not None:

@@ -612,10 +612,10 @@ def bn_stats(x, N, Cc, SP):
 def bn_finalize(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt):
     """-> (save_mean, save_invstd, scale, shift); running stats updated in place."""
     Cc, P = ss.shape
-    # rows padded to a multiple of 16 + 16 floats (zeros): a consumer that applies (scale, shift) while it stages its input
+    # rows padded to a multiple of 16 + 16 floats: a consumer that applies (scale, shift) while it stages its input
     # (conv_fwd_xf) reads whole 16-channel chunks
     Cp = -(-Cc // 16) * 16 + 16
-    out = torch.zeros((4, Cp), dtype=F32, device=ss.device)
+    out = torch.empty((4, Cp), dtype=F32, device=ss.device)      # (the pad is never used as a number: consumers select on c < C)
     H.call('gca_bn_finalize', ptr(ss), ptr(sq), P, Cc, float(count), ptr(gamma), ptr(beta), float(eps),
            float(momentum), ptr(rmean), ptr(rvar), ptr(nbt), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(out[3]),
            stream())
