@@ -98,6 +98,9 @@ def test_configs1_moco_steps_under_tuned_launch_shapes(pkg, tuned_launch_shapes,
         for k_, v in errs.items():
             assert v < (1e-3 if k_ != 'rank_rows_off' else 0.1), (math, step, k_, v)
             worst[k_] = max(worst.get(k_, 0.0), v)
+        # (the backward of every layer of this step, on the oracle's own activations and at a 5e-5 bar, is
+        # tests/test_gpu_layers.py::test_configs1_every_layer_fwd_dgrad_wgrad_under_tuned_shapes -- THAT is the check that sees a
+        # wrong dgrad / wgrad of one layer class; what follows is the plumbing check of the update itself.)
         # the update: (p_after - p_before) against the oracle's, per tensor.  Both sides are fp32 implementations, and the
         # gradients of this network move by 2e-2 (median over tensors; 1.5e-1 worst) when the clips are perturbed by 1e-6
         # -- ReLU / max-pool decisions of activations within rounding of a tie (tools/grad_tuned_vs_heuristic.py --perturb;
@@ -205,6 +208,10 @@ def test_configs3_assembled_s3d_graph_simsiam(pkg, math):
         print('configs[3] %s: gradient median error %.3e; fp32 CPU oracle %.3e, perturbed %s'
               % (math, med(errs), med(e32), ['%.3e' % med(e) for e in e32_alt]))
         assert med(errs) < 3 * yard + 1e-4, (med(errs), med(e32), [med(e) for e in e32_alt])
+        # a FIXED ceiling next to the moving yardstick (observed over the kernel generations of rounds 2-3: 0.10-0.14 for either
+        # arithmetic; the fp32 CPU oracle itself 0.04-0.10).  The well-conditioned checks that can see one wrong kernel are the
+        # per-op gates at these sites and sizes: tests/test_gpu_layers.py::test_configs3_graph_block_at_224_sites_vs_fp64_oracle
+        assert med(errs) < 0.2, med(errs)
         # the graph blocks' own parameters (8-, 4- and 2-node sites), the stem and the predictor head
         pre = 'model.encoder.base_model.'
         for n in (pre + 'base.5.0.gcns.0.conv.weight', pre + 'base.5.0.g_q.0.weight', pre + 'base.9.0.g_k.0.weight',
