@@ -31,6 +31,11 @@ extern "C" {
 
 int gca_version(void);
 
+/* Diagnostic: workgroups of the LDS-halo conv kernel with `tm` x `tn` tiles per wave (rows 32 tm, columns 128 tn) in
+ * arithmetic `math` that the runtime co-schedules on one CU at `lds_bytes` of dynamic LDS; -1 for a shape the entry does not
+ * know.  (DESIGN.md quotes it for the dominant kernel; nothing on the product path calls it.) */
+int gca_conv_halo_occupancy(int tm, int tn, int math, int64_t lds_bytes);
+
 /* Arithmetic of the convolution kernels (forward, dgrad, wgrad; tensors stay fp32 in HBM in every mode):
  *   0  f32:     v_mfma_f32_32x32x2_f32, bitwise an fmaf chain (157 TFLOP/s peak)
  *   1  bf16x3:  every fp32 operand is split in the kernel into hi = bf16(x), lo = bf16(x - hi); a product becomes

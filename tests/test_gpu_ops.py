@@ -957,6 +957,68 @@ def test_conv_wgrad_streaming_spatial_kernel(ops, shape, K):
         ops.set_conv_math(default)
 
 
+@pytest.mark.parametrize('shape,K,k,p', [
+    ((3, 3, 4, 28, 48), 110, (1, 7, 7), (0, 3, 3)),     # R(2+1)D-18 stem kind: four row tiles, OW = 24 (second step half valid)
+    ((2, 3, 5, 36, 64), 64, (1, 7, 7), (0, 3, 3)),      # S3D stem kind: two row tiles, the two waves of a tile set share the steps
+    ((2, 3, 6, 20, 32), 64, (7, 7, 7), (3, 3, 3)),      # 3D-ResNet stem kind: two tap planes per workgroup, planes in the padding
+    ((2, 3, 4, 22, 48), 20, (3, 5, 7), (1, 2, 3)),      # K < 32, 5 x 7 taps, odd OH
+    ((2, 1, 3, 16, 32), 40, (3, 7, 5), (1, 3, 2)),      # one input channel, 5 taps along W
+    ((2, 4, 2, 18, 32), 70, (1, 5, 7), (0, 2, 3)),      # four input channels (140 columns), K tile tail
+    ((1, 3, 3, 40, 16), 33, (1, 7, 7), (0, 3, 3)),      # OW = 8: half a step per row
+])
+def test_conv_wgrad_stem_kernel(ops, shape, K, k, p):
+    """conv3d_wgrad_stem.hip (tune_wgrad_tile 14): the weight gradient of the <= 4-channel, stride-(1,2,2) stem convs (parity
+    phases of every input row staged once, rows rolling over the output rows, dY by LDS-DMA as fragments) over split counts
+    from one workgroup per tap-plane group to chunks of 8 output rows, all three arithmetics it serves (bf16x6, bf16x3, fp16
+    storage), += and a batch-strided x view, vs ATen in fp64."""
+    torch.manual_seed(shape[3] * 5 + K)
+    N, C, D, Hh, W = shape
+    big = torch.randn(N, 2 * C, D, Hh, W)
+    x = big[:, C:]
+    w = torch.randn((K, C) + k) * 0.1
+    xr, wr = x.double().clone().requires_grad_(True), w.double().clone().requires_grad_(True)
+    yr = F.conv3d(xr, wr, None, (1, 2, 2), p)
+    dy = torch.randn(yr.shape)
+    yr.backward(dy.double())
+    units = N * yr.shape[2]
+    default = ops.get_conv_math()
+    try:
+        for mode, tol in (('bf16x6', 1e-5), ('bf16x3', 5e-5), ('fp16', 2e-3)):
+            ops.set_conv_math(mode)
+            f16 = mode == 'fp16'
+            bigd = big.to(DEV).half() if f16 else big.to(DEV)
+            dyd = dy.to(DEV).half() if f16 else dy.to(DEV)
+            ref = wr.grad
+            if f16:                                     # the fp16 path differentiates the ROUNDED tensors
+                ref = torch.nn.grad.conv3d_weight(bigd[:, C:].double().cpu(), w.shape, dyd.double().cpu(), stride=(1, 2, 2), padding=p)
+                tol = 1e-5
+            xd = bigd[:, C:]
+            for view in ((False,) if f16 else (False, True)):
+                xin = xd if view else xd.contiguous()
+                plan = ops.ConvPlan(N, C, D, Hh, W, K, k, (1, 2, 2), p, DEV, x_batch_stride=xin.stride(0) if view else 0, act_f16=f16)
+                plan.tuned = [True, True, True]
+                for sp in sorted({1, 2, units, 4 * units}):
+                    plan.g.tune_wgrad_tile, plan.g.tune_wgrad_splits = 14, sp
+                    plan.refresh()
+                    cfg = plan.cfg(2)
+                    assert cfg[3] & 255 == 14, cfg
+                    dw = torch.full_like(w, 0.5).to(DEV)
+                    ops.conv_wgrad(plan, xin, dyd, dw, accumulate=True)
+                    assert rel_err(dw - 0.5, ref) < tol, (mode, view, sp, cfg)
+                    ops.conv_wgrad(plan, xin, dyd, dw, accumulate=False)
+                    assert rel_err(dw, ref) < tol, (mode, view, sp, cfg)
+        # geometries it must refuse: unit stride, > 4 input channels, 9 taps along W
+        ops.set_conv_math('bf16x6')
+        for shp, kk, s, pp in (((2, 3, 2, 16, 32), (1, 7, 7), 1, (0, 3, 3)), ((2, 8, 2, 16, 32), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+                               ((2, 3, 2, 16, 32), (1, 3, 9), (1, 2, 2), (0, 1, 4))):
+            plan = ops.ConvPlan(*shp, 32, kk, s, pp, DEV)
+            plan.g.tune_wgrad_tile = 14
+            plan.refresh()
+            assert plan.cfg(2)[3] & 255 != 14
+    finally:
+        ops.set_conv_math(default)
+
+
 @pytest.mark.parametrize('shape,K,kd,sd,pd', [
     ((4, 48, 1, 4, 4), 40, 3, 1, 1),        # D = 1: only the centre tap meets data (layer4 of R(2+1)D-18)
     ((3, 32, 2, 5, 5), 24, 3, 2, 1),        # D = 2, temporal stride 2 -> OD = 1: taps 1, 2

@@ -44,6 +44,7 @@ _GP, _PP = C.POINTER(ConvGeom), C.POINTER(PoolGeom)
 # name -> (restype, argtypes): exactly the declarations of include/gca_hip.h
 SIGNATURES = {
     'gca_version': (c_i32, []),
+    'gca_conv_halo_occupancy': (c_i32, [c_i32, c_i32, c_i32, c_i64]),
     'gca_set_conv_math': (c_i32, [c_i32]),
     'gca_get_conv_math': (c_i32, []),
     'gca_conv_pack_elems': (c_i64, [_GP, c_i32]),

@@ -1290,7 +1290,7 @@ int conv_math() {
 
 extern "C" {
 
-int gca_version(void) { return 14; }
+int gca_version(void) { return 15; }
 
 int gca_set_conv_math(int mode) {
   if (mode < 0 || mode > 2) return GCA_EINVAL;

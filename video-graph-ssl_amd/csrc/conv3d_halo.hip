@@ -448,3 +448,20 @@ int halo_launch(const HaloCfg& c, const HaloParams& hp_in, const void* src, cons
 }
 
 }  // namespace gca_conv
+
+// Diagnostic: workgroups of conv_halo_kernel<tm, tn, math> the runtime co-schedules per CU at `lds_bytes` of dynamic LDS
+// (registers + LDS as the hardware allocates them); -1 for a shape that is not instantiated.
+extern "C" int gca_conv_halo_occupancy(int tm, int tn, int math, int64_t lds_bytes) {
+  int n = -1;
+#define GCA_HO(A, B, M)                                                                                                   \
+  if (tm == A && tn == B && math == M) {                                                                                  \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<A, B, M>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                        160 << 10);                                                                                       \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_halo_kernel<A, B, M>, 256, (size_t)lds_bytes) != hipSuccess) \
+      n = -1;                                                                                                             \
+  }
+  GCA_HO(2, 2, 2) GCA_HO(2, 2, 0) GCA_HO(5, 1, 2) GCA_HO(4, 1, 2) GCA_HO(3, 1, 2) GCA_HO(2, 1, 2) GCA_HO(1, 1, 2)
+#undef GCA_HO
+  return n;
+}
+

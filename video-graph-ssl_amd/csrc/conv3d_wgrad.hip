@@ -674,7 +674,18 @@ void wgrad_plan(const gca_conv_geom* g, WgradPlan& pl) {
   p.math = resolve_math(g->tune_wgrad_math, g->act_f16);
   p.half = p.math == 3;
   pl.ts = 0;
-  if (g->tune_wgrad_tile >= 11 && wgrad_ts_ok(g, g->tune_wgrad_tile, p.math)) {
+  if (g->tune_wgrad_tile == 14 && wgrad_stem_ok(g, p.math)) {
+    // conv3d_wgrad_stem.hip: whole dW per workgroup group, split over (clip, od) units
+    pl.ts = 14;
+    pl.shape = 0;
+    p.tilesM = 1;
+    p.tilesN = 1;
+    p.splits = wgrad_stem_splits(g, g->tune_wgrad_splits);
+    p.kt_per_split = 0;
+    p.chk = 0;
+    return;
+  }
+  if (g->tune_wgrad_tile >= 11 && g->tune_wgrad_tile <= 13 && wgrad_ts_ok(g, g->tune_wgrad_tile, p.math)) {
     // conv3d_wgrad_ts.hip: its own tiling (32*TM x 32 x all taps per wave) and split (over clip x position-chunk units)
     pl.ts = g->tune_wgrad_tile;
     pl.shape = 0;
@@ -800,6 +811,11 @@ static int wgrad_partial_launch(const gca_conv_geom* g, const void* x_, const vo
   float* slab = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)nblk);
   int rc;
+  if (pl.ts == 14) {
+    if (in_scale || ((uintptr_t)x % 4) || ((uintptr_t)dy % 16)) return GCA_EINVAL;
+    rc = wgrad_stem_launch(g, p.math, p.splits, x_, dy_, slab, st);
+    return rc ? rc : p.splits;
+  }
   if (pl.ts) {
     // 16-byte DMA pieces; rows of the (1,3,3) kernel start at arbitrary columns anyway, so only dword alignment matters there
     if (pl.ts != 13 && (((uintptr_t)x % 16) || ((uintptr_t)dy % 16))) return GCA_EINVAL;

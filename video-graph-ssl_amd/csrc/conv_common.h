@@ -100,7 +100,7 @@ inline bool geom_ok(const gca_conv_geom* g) {
   for (int v : {g->tune_fwd_box, g->tune_dgrad_box}) if (v < 0 || v > 0xffffff) return false;
   if (g->act_f16 != 0 && g->act_f16 != 1) return false;
   for (int v : {g->tune_fwd_splits, g->tune_dgrad_splits, g->tune_wgrad_splits}) if (v < 0 || v > 1024) return false;
-  if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 13) return false;     // 1..10 tile shapes of conv_wgrad_kernel, 11 / 12 the streaming temporal kernel, 13 the streaming (1,3,3) kernel
+  if (g->tune_wgrad_tile < 0 || g->tune_wgrad_tile > 14) return false;     // 1..10 tile shapes of conv_wgrad_kernel, 11 / 12 the streaming temporal kernel, 13 the streaming (1,3,3) kernel, 14 the stem kernel
   for (int v : {g->tune_fwd_math, g->tune_dgrad_math, g->tune_wgrad_math}) if (v < 0 || v > 3) return false;
   for (int v : {g->tune_fwd_tail, g->tune_dgrad_tail}) if (v < 0 || (v != 0 && ((v & 255) < 1 || (v & 255) > 4))) return false;
   return true;
@@ -113,6 +113,10 @@ bool wgrad_ts_ok(const gca_conv_geom* g, int tile, int math);
 int wgrad_ts_splits(const gca_conv_geom* g, int tile, int want);
 int wgrad_ts_launch(const gca_conv_geom* g, int tile, int math, int splits, const float* x, const float* dy, float* slab,
                     hipStream_t st, const float* in_scale = nullptr, const float* in_shift = nullptr);
+// conv3d_wgrad_stem.hip: weight gradient of the <= 4-channel, stride-2 stem convolutions (tune_wgrad_tile 14)
+bool wgrad_stem_ok(const gca_conv_geom* g, int math);
+int wgrad_stem_splits(const gca_conv_geom* g, int want);
+int wgrad_stem_launch(const gca_conv_geom* g, int math, int splits, const void* x, const void* dy, float* slab, hipStream_t st);
 inline bool unit_stride(const gca_conv_geom* g) { return g->sd == 1 && g->sh == 1 && g->sw == 1; }
 
 

@@ -220,6 +220,16 @@ class ConvPlan:
             tiles = -(-M // 32) * -(-g.C // 32)
             for nb in (256, 512, 768):
                 cands.append((13, max(1, min(units // 4, nb // tiles))))
+        # the stem kernel (conv3d_wgrad_stem.hip, tile 14): <= 4 input channels, stride 2 along H and W; its split is over
+        # (clip, od) units, one workgroup per (split, group of tap planes)
+        if g.C <= 4 and (g.sd, g.sh, g.sw) == (1, 2, 2) and g.K <= 128:
+            units = g.N * ((g.D + 2 * g.pd - g.kd) // g.sd + 1)
+            groups = (-(-g.kd // 2) if g.K <= 64 else g.kd) if g.kd > 1 else 1
+            oh = (g.H + 2 * g.ph - g.kh) // g.sh + 1
+            for nb in (256, 512, 1024, 2048):
+                sp = max(1, min(units * max(1, oh // 8), nb // groups))     # (the library chunks the output rows past N * OD units)
+                if sp * M * Nred * 4 <= (256 << 20):
+                    cands.append((14, sp))
         return sorted(set(cands))
 
     # ---- one-off launch tuning ------------------------------------------------------------
