@@ -227,7 +227,7 @@ class ConvPlan:
             groups = (-(-g.kd // 2) if g.K <= 64 else g.kd) if g.kd > 1 else 1
             oh = (g.H + 2 * g.ph - g.kh) // g.sh + 1
             for nb in (256, 512, 1024, 2048):
-                sp = max(1, min(units * max(1, oh // 8), nb // groups))     # (the library chunks the output rows past N * OD units)
+                sp = max(1, min(units * max(1, oh // 8), nb // groups, 1024))     # (the library chunks the output rows past N * OD units)
                 if sp * M * Nred * 4 <= (256 << 20):
                     cands.append((14, sp))
         return sorted(set(cands))
