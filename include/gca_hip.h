@@ -76,7 +76,11 @@ typedef struct {
                                                  and <= 8 taps along W; bf16x3 / bf16x6 / fp16 storage), 8192 | 128 =
                                                  pointwise fp16 GEMM kernel (1x1x1, unit stride, act_f16); split-K factor */
   int32_t tune_dgrad_bm, tune_dgrad_splits;
-  int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile shape index 1..10 (see gca_conv_wgrad_cfg), 0 = heuristic */
+  int32_t tune_wgrad_splits, tune_wgrad_tile;  /* split-K factor; tile: 0 = heuristic, 1..10 = shapes of the gather kernel (see
+                                                * gca_conv_wgrad_cfg), 11 / 12 = streaming temporal kernel (32 / 64 output channels per
+                                                * wave), 13 = streaming (1,3,3) kernel, 14 = stem kernel (<= 4 input channels, stride
+                                                * (1,2,2)); a tile the geometry / arithmetic does not admit falls back to the heuristic
+                                                * (gca_conv_wgrad_cfg reports what will run) */
   int32_t tune_fwd_tail, tune_dgrad_tail;      /* two-phase launch: (short tile rows / 32) | (column tiles run with the tall
                                                   tile << 8); 0 = single launch.  Used only with 128-column tiles, split 1 */
   int32_t tune_fwd_math, tune_dgrad_math, tune_wgrad_math;  /* 0 = the arithmetic set by gca_set_conv_math; 1 + m = run this
