@@ -221,6 +221,17 @@ def kernel_timing(pkg, trainer, args):
             add(_sym(c1, plan.g.tune_dgrad_tail), t, flops, 1, max(1, c1[3] & 255), nbytes)
         t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True), 5, 1)    # includes the split-K reduce
         cw = plan.cfg(2)
+        L_ = pkg.engine.layers
+        if (L_.LAZY_BN and not half and m.__class__.__name__ != 'Lin' and shp[0] * shp[2] * shp[3] * shp[4] > L_.BN_SMALL_ELEMS
+                and ops.conv_xf_ok(plan)):
+            # in the step this conv applies its producer's BatchNorm + ReLU while it stages its input (engine.layers
+            # _conv_input): time THAT form of the forward and of the weight gradient, as rocprofv3 sees them
+            cp = -(-shp[1] // 16) * 16 + 16
+            sc_, sf_ = torch.ones(cp, device='cuda'), torch.zeros(cp, device='cuda')
+            t_x = ev_time_ms(lambda: ops.conv_fwd_xf(plan, x, sc_, sf_, wp0, stats=True), 5, 1)
+            add(_sym(c0, plan.g.tune_fwd_tail), t_x - t_f, 0.0, 2, 0, 0.0)     # replace the plain forward's time, same launches
+            t_f = t_x
+            t = ev_time_ms(lambda: ops.conv_wgrad(plan, x, dy, dw, True, xf=(sc_, sf_)), 5, 1)
         add('conv_wgrad_kernel<%dx%d>%s' % (cw[0], cw[1], ' (fp16 storage)' if half else ''), t, flops, 1, 1, nbytes)
         if args.layer_table:
             log('L%02d in%-22s K=%-4d k=%s s=%s  GF %7.2f  cfg f%s d%s w%s/%d  fwd %7.3f ms %6.1f TF | dgrad %s | wgrad %7.3f ms %6.1f TF'

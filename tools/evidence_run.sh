@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT; cd $R; E=$R/gpurun_out/ev; mkdir -p $E
 GCA_TUNE_CACHE=$E/tune_cache.json timeout -k 10 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $E/bench.json 2> $E/bench.err || { echo bench failed; tail -5 $E/bench.err; exit 1; }
 echo bench done; cp $E/tune_cache.json profiles/tune_cache.json
 ARENA=33.51e6
+export GCA_SEED_CACHE=1
 bash tools/pmc_step.sh > $E/pmc_step.log 2>&1 || { echo pmc_step failed; tail -5 $E/pmc_step.log; exit 2; }
 python tools/pmc_parse.py gpurun_out/pmc_step $ARENA > $E/pmc_traffic.json
 python tools/step_breakdown.py $(ls gpurun_out/pmc_step/trace/*kernel_trace.csv | head -1) 4 > $E/step_breakdown.txt

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgca_hip.so')
+LIB_PATH = os.environ.get('GCA_LIB_PATH') or os.path.join(_HERE, 'libgca_hip.so')      # (GCA_LIB_PATH: A/B runs against another build)
 
 
 class HipLibraryMissing(RuntimeError):
