@@ -77,6 +77,55 @@ def test_conv_arithmetic_mode_is_an_accuracy_floor_host_side(pkg):
         H.lib.gca_set_conv_math(default)
 
 
+def test_weight_gradient_kernel_selection_host_side(pkg):
+    """tune_wgrad_tile (host logic only, no launch): gca_conv_wgrad_cfg reports the kernel a weight gradient would run on --
+    the streaming temporal / (1,3,3) kernels (11, 12, 13) and the stem kernel (14) only where geometry and arithmetic admit
+    them, the gather kernel's shape otherwise; split counts follow the unit counts of each kernel; the work-space size
+    follows the split count."""
+    H = pkg._hip
+    import ctypes as C
+    out = (C.c_int32 * 4)()
+
+    def geom(N, Cin, D, Hh, W, K, k, s, p, f16=0):
+        od, oh, ow = [(d + 2 * pp - kk) // ss + 1 for d, pp, kk, ss in zip((D, Hh, W), p, k, s)]
+        g = H.ConvGeom(N, Cin, D, Hh, W, K, *k, *s, *p, od, oh, ow, 0)
+        g.act_f16 = f16
+        return g
+
+    def tile(g, t, sp=0):
+        g.tune_wgrad_tile, g.tune_wgrad_splits = t, sp
+        assert H.lib.gca_conv_wgrad_cfg(C.byref(g), out) == 0
+        return out[3] & 255, out[2]
+
+    default = H.lib.gca_get_conv_math()
+    try:
+        H.lib.gca_set_conv_math(2)                                              # bf16x6
+        stem = geom(32, 3, 16, 112, 112, 110, (1, 7, 7), (1, 2, 2), (0, 3, 3))
+        assert tile(stem, 14, 256) == (14, 256)
+        assert tile(stem, 14, 1024) == (14, 1024)                               # 512 (clip, od) units x 2 row chunks
+        assert tile(stem, 14, 0)[0] == 14 and 1 <= tile(stem, 14, 0)[1] <= 1024
+        ws = [H.lib.gca_conv_wgrad_ws_bytes(C.byref(stem)) for _ in [tile(stem, 14, 128)]][0]
+        assert ws == 128 * 110 * 3 * 49 * 4
+        assert tile(stem, 11)[0] not in (11, 14) and tile(stem, 13)[0] not in (13, 14)      # not a temporal / (1,3,3) conv
+        r3d = geom(16, 3, 32, 224, 224, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3), f16=1)
+        assert tile(r3d, 14, 512) == (14, 512)                                  # fp16 storage: the f16 instantiation
+        r3d32 = geom(16, 3, 32, 224, 224, 64, (7, 7, 7), (1, 2, 2), (3, 3, 3))
+        assert tile(r3d32, 14, 512)[0] != 14                                    # fp32 tensors, bf16x6 parts: the rows do not fit the LDS
+        for bad in (geom(4, 3, 8, 56, 56, 64, (1, 7, 7), (1, 1, 1), (0, 3, 3)),          # unit stride
+                    geom(4, 8, 8, 56, 56, 64, (1, 3, 3), (1, 2, 2), (0, 1, 1)),          # 8 input channels
+                    geom(4, 3, 8, 56, 56, 200, (1, 7, 7), (1, 2, 2), (0, 3, 3)),         # > 128 output channels
+                    geom(4, 3, 8, 56, 54, 64, (1, 7, 7), (1, 2, 2), (0, 3, 3))):         # OW = 27: not a multiple of 8
+            assert tile(bad, 14)[0] != 14
+        temporal = geom(32, 144, 8, 28, 28, 64, (3, 1, 1), (1, 1, 1), (1, 0, 0))
+        assert tile(temporal, 11, 64)[0] == 11 and tile(temporal, 12, 64)[0] == 12 and tile(temporal, 14)[0] != 14
+        spatial = geom(32, 64, 8, 28, 28, 144, (1, 3, 3), (1, 1, 1), (0, 1, 1))
+        assert tile(spatial, 13, 64)[0] == 13 and tile(spatial, 11)[0] != 11
+        H.lib.gca_set_conv_math(0)                                              # fp32 MFMA: none of the split-product kernels
+        assert tile(stem, 14)[0] != 14 and tile(temporal, 11)[0] != 11 and tile(spatial, 13)[0] != 13
+    finally:
+        H.lib.gca_set_conv_math(default)
+
+
 @pytest.mark.parametrize('name,octor', [('R2P1D18', lambda o: o.R2Plus1D(18)), ('S3D', lambda o: o.S3D()),
                                         ('R3D18', lambda o: o.R3D(18, 112, 16))])
 def test_backbones_match_oracle_state_dict(pkg, name, octor):
