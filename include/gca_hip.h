@@ -216,6 +216,18 @@ int gca_bn_finalize(const float* stat_sum, const float* stat_sq, int64_t P, int6
                     const float* gamma, const float* beta, float eps, float momentum,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
                     float* save_mean, float* save_invstd, float* scale, float* shift, void* stream);
+/* A conv whose launch shape splits the reduction, followed by a small BatchNorm (N*SP <= 32768), in two launches instead of
+ * three.  gca_conv_fwd_slabs runs the forward class and LEAVES the fp32 slabs [splits][K][N*SP] in `ws` (no bias; fp32
+ * tensors only; GCA_EINVAL when the pinned launch shape does not split -- gca_conv_kernel_cfg tells beforehand);
+ * gca_bn_train_fwd_slabs folds them in the finishing kernel's order (same bits for y), writes y (the backward pass reads
+ * it), takes the batch statistics from those values in fp64 and normalises: finalize + apply as gca_bn_train_fwd.
+ * Replaces the conv -> BatchNorm link of resnet2p1d.py:66-85 / s3d_1.py:43-47 on the deep, narrow layers. */
+int gca_conv_fwd_slabs(const gca_conv_geom* g, const void* x, const float* wpack, const int32_t* table, void* ws,
+                       int32_t* out_splits, void* stream);
+int gca_bn_train_fwd_slabs(const float* slabs, int64_t splits, double count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* save_mean, float* save_invstd, float* scale, float* shift, float* y, const float* residual,
+                           int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream);
 /* gca_bn_finalize followed by gca_bn_apply behind one call (one LAUNCH when N*SP is small: the deep layers, and
  * every layer of a small batch, are launch-latency bound).  count must equal N*SP. */
 int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int64_t C, double count,

@@ -846,6 +846,50 @@ def test_bn_train_fwd_and_small_bwd_equal_the_separate_passes(ops, N, C, SP, res
         assert torch.equal(dx2, dx) and torch.equal(dg2, dg)
 
 
+@pytest.mark.parametrize('shape,K,k,p,res,halo', [
+    ((4, 96, 2, 7, 7), 80, (3, 1, 1), (1, 0, 0), True, False),        # gather kernel, residual, K tile tail
+    ((3, 64, 2, 6, 6), 48, (1, 3, 3), (0, 1, 1), False, True),        # LDS-halo kernel
+    ((2, 256, 1, 4, 4), 130, (1, 1, 1), (0, 0, 0), False, False),     # pointwise, 32 positions
+])
+def test_conv_splitk_slabs_folded_by_the_batchnorm_kernel(ops, shape, K, k, p, res, halo):
+    """gca_conv_fwd_slabs + gca_bn_train_fwd_slabs (a split-K conv in front of a small BatchNorm: the BatchNorm kernel folds
+    the slabs) against gca_conv_fwd (which finishes its slabs itself) + gca_bn_train_fwd: the same bits for y, the
+    statistics and z to fp32 rounding (they skip the fp32 partial sums here), running statistics updated once."""
+    torch.manual_seed(K)
+    N, C, D, Hh, W = shape
+    x = torch.randn(shape, device=DEV)
+    w = torch.randn((K, C) + k, device=DEV) * 0.1
+    gam, bet = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV)
+    plan = ops.ConvPlan(N, C, D, Hh, W, K, k, 1, p, DEV)
+    plan.tuned = [True, True, True]
+    for sp in (2, 3, 5):
+        plan.g.tune_fwd_bm, plan.g.tune_fwd_splits = (2048 + 64 if halo else 64), sp
+        plan.refresh()
+        if plan.cfg(0)[2] < 2:
+            continue
+        wp = ops.conv_pack(plan, 0, w)
+        SP = plan.out_shape[2] * plan.out_shape[3] * plan.out_shape[4]
+        r = torch.randn(plan.out_shape, device=DEV) if res else None
+
+        def fresh():
+            return torch.zeros(K, device=DEV), torch.ones(K, device=DEV), torch.zeros((), dtype=torch.long, device=DEV)
+        rm0, rv0, nb0 = fresh()
+        y0, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True)
+        z0, mean0, invstd0, scale0, shift0 = ops.bn_train_fwd(ss, sq, N * SP, gam, bet, 1e-5, 0.1, rm0, rv0, nb0, y0, r, True, N, K, SP)
+        rm1, rv1, nb1 = fresh()
+        y1, z1, mean1, invstd1, scale1, shift1 = ops.conv_bn_small_fwd(plan, x, wp, N * SP, gam, bet, 1e-5, 0.1, rm1, rv1, nb1, r, True)
+        assert torch.equal(y0, y1), (sp, plan.cfg(0))
+        assert rel_err(mean1, mean0) < 1e-6 and rel_err(invstd1, invstd0) < 1e-6 and rel_err(z1, z0) < 2e-6
+        assert rel_err(rm1, rm0) < 1e-6 and rel_err(rv1, rv0) < 1e-6 and int(nb1) == 1
+        # a channel slice of a wider buffer as the destination (Inception concat)
+        wide = torch.zeros((N, K + 5) + tuple(plan.out_shape[2:]), device=DEV)
+        rm2, rv2, nb2 = fresh()
+        ops.conv_bn_small_fwd(plan, x, wp, N * SP, gam, bet, 1e-5, 0.1, rm2, rv2, nb2, r, True, out=wide[:, 3:3 + K])
+        assert torch.equal(wide[:, 3:3 + K], z1) and float(wide[:, :3].abs().max()) == 0.0 and float(wide[:, 3 + K:].abs().max()) == 0.0
+        return
+    pytest.fail('no launch shape with a split reduction was available')
+
+
 @pytest.mark.parametrize('shape,K,kd,pd', [
     ((2, 40, 9, 4, 8), 48, 7, 3),       # stem-temporal kind: C, K not multiples of 32 (tile tails), D > kd, HW = 32
     ((3, 33, 5, 4, 4), 70, 7, 3),       # D < kd: most taps of most planes lie in the padding; HW = 16; odd unit count

@@ -108,6 +108,9 @@ SIGNATURES = {
     'gca_conv_xf_ok': (c_i32, [_GP]),
     'gca_conv_fwd_xf': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     'gca_conv_wgrad_xf': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    'gca_conv_fwd_slabs': (c_i32, [_GP, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    'gca_bn_train_fwd_slabs': (c_i32, [c_vp, c_i64, c_f64, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                       c_vp, c_i32, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp]),
     'gca_reduce_jobs_finalize_host': (c_i64, [c_vp, c_i64]),
     'gca_splitk_reduce_batched': (c_i32, [c_vp, c_i64, c_i64, c_vp]),
     'gca_clip_prepare': (c_i32, [c_vp, c_i64, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp]),

@@ -369,6 +369,100 @@ __global__ __launch_bounds__(256) void bn_fwd_small_kernel(
   }
 }
 
+// The same for a conv whose split-K slabs are still un-folded (gca_conv_fwd_slabs): the workgroup of channel c first folds
+// slab[s][c][n] over s in the fixed order 0, 1, ... (the bits conv_splitk_finish_kernel would write), stores the conv output
+// y -- the backward pass needs it -- and takes the batch statistics from those values in fp64; then finalize and apply as
+// above.  One launch instead of three (finish, finalize + apply), and the statistics skip the fp32 partial sums.
+__global__ __launch_bounds__(256) void bn_fwd_small_slab_kernel(
+    const float* __restrict__ slab, int splits, double count,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ smean, float* __restrict__ sinvstd,
+    float* __restrict__ scale, float* __restrict__ shift, long long* __restrict__ nbt,
+    float* __restrict__ y, const float* __restrict__ res, int relu, int N, int C, int SP, long long zs,
+    float* __restrict__ z) {
+  __shared__ double sh[4];
+  __shared__ float ab[2];
+  const int c = blockIdx.x;
+  if (nbt && c == 0 && threadIdx.x == 0) *nbt += 1;
+  const int total = N * SP;
+  const long long sstride = (long long)C * total;
+  const float* s0 = slab + (long long)c * total;
+  double s = 0.0, q = 0.0;
+  constexpr int UF = 4;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * UF) {
+    float v[UF];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) v[u] = 0.f;
+    int k = 0;
+    for (; k + 2 <= splits; k += 2) {                 // 2 x UF loads in flight, summed in the fixed order 0, 1, 2, ...
+      float a[UF], b[UF];
+#pragma unroll
+      for (int u = 0; u < UF; ++u) {
+        const int i = min(i0 + 256 * u, total - 1);
+        a[u] = s0[(long long)k * sstride + i];
+        b[u] = s0[(long long)(k + 1) * sstride + i];
+      }
+#pragma unroll
+      for (int u = 0; u < UF; ++u) { v[u] += a[u]; v[u] += b[u]; }
+    }
+    if (k < splits) {
+#pragma unroll
+      for (int u = 0; u < UF; ++u) v[u] += s0[(long long)k * sstride + min(i0 + 256 * u, total - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      const int i = i0 + 256 * u;
+      if (i >= total) break;
+      const int n = i / SP, sp = i - n * SP;
+      y[((long long)n * C + c) * SP + sp] = v[u];
+      s += (double)v[u]; q += (double)v[u] * (double)v[u];
+    }
+  }
+  s = gca_block_sum256_d(s, sh);
+  q = gca_block_sum256_d(q, sh);
+  if (threadIdx.x == 0) {
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0.0) var = 0.0;
+    const double is = 1.0 / sqrt(var + (double)eps);
+    if (smean) smean[c] = (float)m;
+    if (sinvstd) sinvstd[c] = (float)is;
+    if (rmean) rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * m);
+    if (rvar) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unb);
+    }
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    const float sc = g * (float)is;
+    const float sf = b - (float)m * sc;
+    scale[c] = sc; shift[c] = sf;
+    ab[0] = sc; ab[1] = sf;
+  }
+  __threadfence_block();                               // the y values of this channel are re-read by other threads below
+  __syncthreads();
+  const float sc = ab[0], sf = ab[1];
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * UF) {
+    float xv[UF], rv[UF];
+    long long zi[UF];
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      const int i = min(i0 + 256 * u, total - 1);
+      const int n = i / SP, sp = i - n * SP;
+      const long long xi = ((long long)n * C + c) * SP + sp;
+      zi[u] = (long long)n * zs + (long long)c * SP + sp;
+      xv[u] = y[xi];
+      rv[u] = res ? res[xi] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UF; ++u) {
+      if (i0 + 256 * u >= total) break;
+      float v = xv[u] * sc + sf + rv[u];
+      if (relu) v = fmaxf(v, 0.f);
+      z[zi[u]] = v;
+    }
+  }
+}
+
 // Whole BatchNorm backward of one channel in ONE workgroup (small N*SP: the deep, narrow layers and every layer of
 // a small batch): pass 1 reduces (sum dz, sum dz*xhat) in fp64, the block derives the coefficients and accumulates
 // dgamma / dbeta, pass 2 re-reads the (L2-resident) operands and writes dx (+ the residual gradient).  Replaces
@@ -634,6 +728,21 @@ int gca_bn_train_fwd(const float* stat_sum, const float* stat_sq, int64_t P, int
   return bn_train_fwd_t<float>(stat_sum, stat_sq, P, C, count, gamma, beta, eps, momentum, running_mean, running_var,
                                num_batches_tracked, save_mean, save_invstd, scale, shift, (const float*)x,
                                (const float*)residual, relu, N, SP, (float*)z, z_batch_stride, stream);
+}
+
+int gca_bn_train_fwd_slabs(const float* slabs, int64_t splits, double count, const float* gamma, const float* beta, float eps,
+                           float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* save_mean, float* save_invstd, float* scale, float* shift, float* y, const float* residual,
+                           int relu, int64_t N, int64_t C, int64_t SP, float* z, int64_t z_batch_stride, void* stream) {
+  if (!slabs || splits < 2 || splits > 1024 || count <= 0 || !scale || !shift || !y || !z || N <= 0 || C <= 0 || SP <= 0)
+    return GCA_EINVAL;
+  if (N * SP > BN_SMALL_ELEMS || N * C * SP >= (1LL << 31)) return GCA_EINVAL;       // the one-workgroup-per-channel regime only
+  if (z_batch_stride != 0 && z_batch_stride < C * SP) return GCA_EINVAL;
+  const long long zs = z_batch_stride ? z_batch_stride : C * SP;
+  hipLaunchKernelGGL(bn_fwd_small_slab_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, slabs, (int)splits, count,
+                     gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_invstd, scale, shift,
+                     (long long*)num_batches_tracked, y, residual, relu, (int)N, (int)C, (int)SP, zs, z);
+  return gca_launch_status();
 }
 
 int gca_bn_apply(const void* x, const float* scale, const float* shift, const void* residual,

@@ -713,6 +713,10 @@ __global__ __launch_bounds__(256) void conv_igemm_2phase_kernel(
 
 // Split-K finishing pass, grid (channels, parts): sum the slabs in fixed order, add bias, (+=) store in
 // NCDHW (through the class's destination map), and emit the BN partial sums [K][parts].
+// gca_conv_fwd_slabs: the split-K classes leave their slabs un-finished (the BatchNorm that follows folds them)
+thread_local bool t_leave_slabs = false;
+thread_local int t_left_splits = 0;
+
 constexpr int FINISH_CHUNK = 1024;      // columns per finishing block: split-K grids are small, so many short blocks (4 columns per thread;
                                         // issuing the slab loads of all four columns together was measured: 9.1 vs 8.6 us per launch, not kept)
 template <typename T>
@@ -1197,6 +1201,7 @@ int run_class(const IgemmCfg& c, int fast, const float* src, const float* apack,
   if (nblk <= 0 || nblk > 0x7fffffffLL) return GCA_EINVAL;
   int rc = launch_tiles(c.bm, c, fast, dim3((unsigned)nblk), st, src, apack, table, bias, dst, ps, pq, slab, p);
   if (rc || c.splits == 1) return rc;
+  if (t_leave_slabs) { t_left_splits = c.splits; return gca_launch_status(); }      // gca_conv_fwd_slabs: the consumer folds them
   if (c.h)
     hipLaunchKernelGGL(conv_splitk_finish_kernel<_Float16>, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, c.splits,
                        bias, reinterpret_cast<_Float16*>(dst), psum, psq, p);
@@ -1225,6 +1230,7 @@ int run_class_halo(const gca_conv_geom* g, const ClassInfo& c, const IgemmCfg& c
   int rc = halo_launch(hc, hp, src, reinterpret_cast<const unsigned char*>(apack), reinterpret_cast<const int*>(table + p.Kpad),
                        bias, dst, cf.splits > 1 ? nullptr : psum, cf.splits > 1 ? nullptr : psq, slab, st);
   if (rc || cf.splits == 1) return rc;
+  if (t_leave_slabs) { t_left_splits = cf.splits; return gca_launch_status(); }     // gca_conv_fwd_slabs: the consumer folds them
   p.splits = cf.splits; p.P = hp.g.P;
   if (cf.h)
     hipLaunchKernelGGL(conv_splitk_finish_kernel<_Float16>, dim3((unsigned)p.DK, (unsigned)p.P), dim3(256), 0, st, slab, cf.splits,
@@ -1517,6 +1523,19 @@ int gca_conv_fwd(const gca_conv_geom* g, const void* x_, const float* wpack, con
                           reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
   return run_class(cf, fast_of(c.ntaps), x, wpack, reinterpret_cast<const int2*>(table), bias,
                    y, stat_sum, stat_sq, reinterpret_cast<float*>(ws), p, (hipStream_t)stream);
+}
+
+int gca_conv_fwd_slabs(const gca_conv_geom* g, const void* x, const float* wpack, const int32_t* table, void* ws,
+                       int32_t* out_splits, void* stream) {
+  if (!out_splits || !ws || !geom_ok(g) || g->act_f16) return GCA_EINVAL;
+  t_leave_slabs = true; t_left_splits = 0;
+  // (y is never written in this mode; the pointer only has to be non-null for the argument check)
+  const int rc = gca_conv_fwd(g, x, wpack, table, nullptr, ws, nullptr, nullptr, ws, stream);
+  t_leave_slabs = false;
+  if (rc) return rc;
+  if (t_left_splits < 2) return GCA_EINVAL;             // this launch shape does not split: the caller must use gca_conv_fwd
+  *out_splits = t_left_splits;
+  return GCA_OK;
 }
 
 int gca_conv_xf_ok(const gca_conv_geom* g) {

@@ -276,11 +276,20 @@ def f_conv_bn_act(tape, conv, bn, xv, relu=True, residual=None, out=None):
             and N * SP > BN_SMALL_ELEMS)
     z = None
     if train:
-        if xf is not None:
+        fused = (ops.FUSE_SPLITK_BN and xf is None and not lazy and plan.tuned[0] and x.dtype is torch.float32
+                 and N * SP <= BN_SMALL_ELEMS and conv.bias is None and plan.cfg(0)[2] > 1 and plan.fwd_ws > 0)
+        if fused:
+            # the conv's split-K slabs go straight into the BatchNorm kernel: no finishing launch
+            y, z, mean, invstd, scale, shift = ops.conv_bn_small_fwd(
+                plan, x, wp, N * SP, bn.weight.data, bn.bias.data, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                bn.num_batches_tracked, None if residual is None else residual.t, relu, out=out)
+        elif xf is not None:
             y, (ss, sq) = ops.conv_fwd_xf(plan, x, xf[0], xf[1], wp, stats=True)
         else:
             y, (ss, sq) = ops.conv_fwd(plan, x, wp, None, stats=True, w_raw=conv.weight.data)
-        if lazy:
+        if fused:
+            pass
+        elif lazy:
             mean, invstd, scale, shift = _bn_scale_shift(bn, ss, sq, N * SP)
         else:
             z, mean, invstd, scale, shift = ops.bn_train_fwd(ss, sq, N * SP, bn.weight.data, bn.bias.data, bn.eps, bn.momentum,

@@ -644,6 +644,28 @@ def bn_train_fwd(ss, sq, count, gamma, beta, eps, momentum, rmean, rvar, nbt, x,
     return z, st[0], st[1], st[2], st[3]
 
 
+# GCA_FUSE_SPLITK_BN=0: a split-K conv in front of a small BatchNorm finishes its slabs in its own launch (A/B runs)
+FUSE_SPLITK_BN = os.environ.get('GCA_FUSE_SPLITK_BN', '1') != '0'
+
+
+def conv_bn_small_fwd(plan, x, wpack, count, gamma, beta, eps, momentum, rmean, rvar, nbt, residual, relu, out=None):
+    """conv forward whose pinned launch shape splits the reduction + training-mode BatchNorm of a small map, in two launches:
+    the conv leaves its slabs in the scratch lane (gca_conv_fwd_slabs), the BatchNorm kernel folds them, writes y and z
+    (gca_bn_train_fwd_slabs).  -> (y, z, save_mean, save_invstd, scale, shift)"""
+    N, K, OD, OH, OW = plan.out_shape
+    SP = OD * OH * OW
+    ws = WS.get(plan.fwd_ws, x.device)
+    splits = C.c_int32(0)
+    H.call('gca_conv_fwd_slabs', plan.gp, ptr(x), ptr(wpack), ptr(plan.table(0)), ptr(ws), C.addressof(splits), stream())
+    y = torch.empty(plan.out_shape, dtype=F32, device=x.device)
+    z = torch.empty_like(y) if out is None else out
+    st = torch.empty((4, K), dtype=F32, device=x.device)
+    H.call('gca_bn_train_fwd_slabs', ptr(ws), int(splits.value), float(count), ptr(gamma), ptr(beta), float(eps), float(momentum),
+           ptr(rmean), ptr(rvar), ptr(nbt), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(y), ptr(residual), int(relu),
+           N, K, SP, ptr(z), _slice_stride(z, K, SP), stream())
+    return y, z, st[0], st[1], st[2], st[3]
+
+
 def bn_fold_eval(gamma, beta, rmean, rvar, eps):
     Cc = rmean.numel()
     out = torch.empty((2, Cc), dtype=F32, device=rmean.device)
