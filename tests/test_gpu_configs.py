@@ -52,7 +52,7 @@ def _force_state(tr, model, ema, contrast, opt):
         else torch.zeros(p.numel()), (0, (-p.numel()) % 256)) for p in model.parameters()]))
 
 
-@pytest.mark.parametrize('math', ['bf16x6', 'f32'])
+@pytest.mark.parametrize('math', ['bf16x6'])     # (fp32 MFMA under the tuned shapes: every layer of it in test_gpu_layers.py)
 def test_configs1_moco_steps_under_tuned_launch_shapes(pkg, tuned_launch_shapes, math):
     """Three full configs[1] iterations (eager, eager, hipGraph capture + replay) with the benchmarked launch configuration
     against oracle.moco.moco_train_step (fp32 CPU) on the same clips, each step started from the oracle's state.  Forward

@@ -65,7 +65,7 @@ def _simulate(pkg, world, steps, init, mem0, w):
     return reps, trace
 
 
-@pytest.mark.parametrize('world,use_graph,math', [(2, False, 'f32'), (2, True, 'f32'), (3, True, 'f32'), (2, True, 'bf16x6')])
+@pytest.mark.parametrize('world,use_graph,math', [(2, False, 'f32'), (3, True, 'f32'), (2, True, 'bf16x6')])
 def test_multi_rank_moco_steps_vs_replica_oracle(pkg, tmp_path, world, use_graph, math):
     import dist_worker as w
     steps = 4
