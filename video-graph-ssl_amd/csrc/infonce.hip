@@ -232,8 +232,7 @@ template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
     const float* __restrict__ q, const float* __restrict__ kpos, const float* __restrict__ queue,
     int b, long long K, int D, float inv_T, float* __restrict__ logits, int ncb,
-    float* part, unsigned* counter, float* __restrict__ lse, int* __restrict__ rank, float* __restrict__ loss, gca_magic md4,
-    int dbg) {
+    float* part, unsigned* counter, float* __restrict__ lse, int* __restrict__ rank, float* __restrict__ loss, gca_magic md4) {
   constexpr int NT = FD / 8;
   __shared__ __attribute__((aligned(16))) float Qs[32 * FP];
   __shared__ __attribute__((aligned(16))) float Ns[WAVES][32 * FP];
@@ -289,7 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
     }
   }
   __syncthreads();
-  if (!(dbg & 8)) {   // positive logits: 32 rows over WAVES waves, 64/(32/WAVES) lanes per row; all key loads up front
+  {   // positive logits: 32 rows over WAVES waves, 64/(32/WAVES) lanes per row; all key loads up front
     constexpr int RPW = WAVES >= 32 ? 1 : 32 / WAVES;
     constexpr int LPR = 64 / RPW;
     constexpr int PPL = (FD / 4 + LPR - 1) / LPR;                   // float4 pieces per lane
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int t = 0; t < ((dbg & 4) ? 1 : nt); ++t) {
+    for (int t = 0; t < nt; ++t) {
       const float4 a = *reinterpret_cast<const float4*>(&Qs[ll * FP + 8 * t + 4 * lh]);
       const float4 bq = *reinterpret_cast<const float4*>(&Nw[ll * FP + 8 * t + 4 * lh]);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq.x, acc, 0, 0, 0);
@@ -356,7 +355,6 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
       const float x = acc[r] * inv_T;
       if (jv && i < b) {
         logits[(long long)i * ld + 1 + j] = x;
-        if (dbg & 2) continue;
         float d = x - mx[r];
         if (d > 24.f) { sm[r] *= __expf(-d); mx[r] = x; d = 0.f; }       // rare: keeps exp(d) far from overflow
         sm[r] += __expf(d);
@@ -377,7 +375,6 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
     if (ll == 31) { Red[wave][0][m] = mxa; Red[wave][1][m] = se; Red[wave][2][m] = ce; }
   }
   __syncthreads();
-  if (dbg & 16) return;
   if (tid < 32) {
     float M = Red[0][0][tid];
 #pragma unroll
@@ -398,7 +395,6 @@ __global__ __launch_bounds__(WAVES * 64) void moco_logits_persist_kernel(
   }
   __syncthreads();
   if (!last_flag) return;
-  if (dbg & 1) { if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
   // ---- last workgroup: fold every workgroup's partials (row = tid & 31; the 2*WAVES slices stride over the workgroups).
   // The loads bypass L1 (sc1), which is what makes them see the other CUs' write-through stores without an acquire fence;
   // sixteen workgroups' triples are in flight per thread (issued one dependent round trip at a time they cost 100 us for
@@ -714,9 +710,8 @@ int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int6
       (((uintptr_t)q | (uintptr_t)queue | (uintptr_t)k) % 16) == 0) {
     // single launch: persistent waves + last-arriving workgroup folds the statistics (moco_logits_persist_kernel)
     const int ncb = (int)gca_ceil_div(K, 32);
-    static int env_waves = -1, env_grid = -1, env_dbg = 0;
+    static int env_waves = -1, env_grid = -1;
     if (env_waves < 0) {
-      const char* d_ = getenv("GCA_NCE_DEBUG"); env_dbg = d_ ? atoi(d_) : 0;      // timing experiments only (wrong results)
       const char* e = getenv("GCA_NCE_WAVES"); env_waves = e ? atoi(e) : 0;
       const char* g = getenv("GCA_NCE_GRID"); env_grid = g ? atoi(g) : 0;
     }
@@ -729,7 +724,7 @@ int gca_moco_logits_fwd(const float* q, const float* k, const float* queue, int6
     const gca_magic md4 = gca_make_magic((unsigned)(D >> 2));
     float* part = reinterpret_cast<float*>(ws);
 #define GCA_PERSIST(W) hipLaunchKernelGGL((moco_logits_persist_kernel<W>), dim3((unsigned)grid), dim3(64 * W), 0, st, q, k, queue, \
-                                          (int)b, (long long)K, (int)D, inv_T, logits, ncb, part, sync_counter, row_lse, rank_ge, loss, md4, env_dbg)
+                                          (int)b, (long long)K, (int)D, inv_T, logits, ncb, part, sync_counter, row_lse, rank_ge, loss, md4)
     if (waves == 8) GCA_PERSIST(8);
     else if (waves == 4) GCA_PERSIST(4);
     else if (waves == 2) GCA_PERSIST(2);
